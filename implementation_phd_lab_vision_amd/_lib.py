@@ -1,0 +1,96 @@
+"""ctypes binding of libr50hip.so (C ABI: include/r50.h).
+
+This is the stub a maintainer of the reference would add to call the MI355X path from
+src/preprocess_resnet_features.py.  There is NO fallback: if the shared
+library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+from typing import Optional
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libr50hip.so"
+CSRC = PKG_DIR / "csrc"
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+
+
+class R50Error(RuntimeError):
+    pass
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("numel", C.c_int64)]
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    """Compile csrc/r50_abi.hip for gfx950 into libr50hip.so (in-tree)."""
+    srcs = [CSRC / "r50_abi.hip", CSRC / "kernels.h", PKG_DIR.parent / "include" / "r50.h"]
+    if LIB_PATH.exists() and not force:
+        if all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs if s.exists()):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(LIB_PATH), str(CSRC / "r50_abi.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise R50Error(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    return LIB_PATH
+
+
+_SIGNATURES = {
+    "r50_version": (C.c_char_p, []),
+    "r50_last_error": (C.c_char_p, [C.c_void_p]),
+    "r50_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+    "r50_destroy": (None, [C.c_void_p]),
+    "r50_load_weights": (C.c_int, [C.c_void_p, C.POINTER(TensorDesc), C.c_int]),
+    "r50_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "r50_forward_layer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int64,
+                                    C.POINTER(C.c_int64), C.c_void_p]),
+    "r50_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "r50_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
+    "r50_profile_reset": (C.c_int, [C.c_void_p]),
+    "r50_profile_collect": (C.c_int, [C.c_void_p]),
+    "r50_profile_count": (C.c_int, [C.c_void_p]),
+    "r50_profile_entry": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "r50_op_conv2d": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "r50_stem_scratch_bytes": (C.c_int64, [C.c_int]),
+    "r50_op_stem": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "r50_op_maxpool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "r50_op_avgpool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libr50hip.so and declare every prototype of include/r50.h.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise R50Error(f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+                       "There is no CPU/PyTorch fallback for this path.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, handle: Optional[int] = None, what: str = "") -> None:
+    if rc != 0:
+        lib = load_library()
+        msg = lib.r50_last_error(C.c_void_p(handle) if handle else None)
+        raise R50Error(f"{what or 'r50 call'} failed (status {rc}): {msg.decode() if msg else '?'}")

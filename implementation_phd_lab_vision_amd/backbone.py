@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's ``backbone`` object for the MI355X path.
+
+The reference builds and calls it as (src/preprocess_resnet_features.py:207-209,242,296)::
+
+    resnet   = models.resnet50(weights=models.ResNet50_Weights.IMAGENET1K_V2)
+    backbone = nn.Sequential(*list(resnet.children())[:-1])
+    backbone = backbone.to(device).eval()
+    feats    = backbone(x).flatten(1).view(Bv, T, -1)      # x: (Bv*T, 3, 224, 224) fp32 NCHW
+
+``ResNet50Backbone`` keeps that surface (``.to(device)``, ``.eval()``, ``__call__`` returning
+``(N, 2048, 1, 1)`` on the same device) and routes the arithmetic to libr50hip.so through the C ABI
+of include/r50.h.  PyTorch is used for device memory and the stream only.  No fallback: without the
+shared library or without a gfx950 GPU the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .weights import FEATURE_DIM, iter_named_tensors, load_state_dict_from_path, synthetic_state_dict, validate_state_dict
+
+PREC_BF16 = 1
+
+
+class ResNet50Backbone:
+    """``resnet50.children()[:-1]`` in eval mode on one MI355X.
+
+    weights: ``state_dict`` (torchvision keys) or ``weights_path`` (local ``resnet50-*.pth``);
+    with neither, seeded synthetic weights (there is no network to fetch IMAGENET1K_V2).
+    """
+
+    def __init__(self, state_dict: Optional[Dict[str, torch.Tensor]] = None, weights_path: Optional[str] = None,
+                 seed: int = 0, max_batch: int = 256, micro_batch: int = 0):
+        if state_dict is None:
+            state_dict = load_state_dict_from_path(weights_path) if weights_path else synthetic_state_dict(seed)
+        validate_state_dict(state_dict)
+        self._sd = state_dict
+        self._max_batch = int(max_batch)
+        self._micro_batch = int(micro_batch)
+        self._handle: Optional[int] = None
+        self._device: Optional[torch.device] = None
+        self.training = False
+
+    # ---- nn.Module-like surface -------------------------------------------------------------
+    def to(self, device) -> "ResNet50Backbone":
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.R50Error(f"ResNet50Backbone runs on an MI355X only (got device '{device}'); "
+                                "there is no CPU fallback in the product path")
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        device = torch.device("cuda", index)
+        if self._handle is not None and self._device == device:
+            return self
+        self._release()
+        lib = _lib.load_library()
+        h = C.c_void_p()
+        _lib.check(lib.r50_create(C.byref(h), index, PREC_BF16, self._max_batch), None, "r50_create")
+        self._handle = h.value
+        self._device = device
+        named = list(iter_named_tensors(self._sd))
+        descs = (_lib.TensorDesc * len(named))()
+        keep = []
+        for i, (name, t) in enumerate(named):
+            keep.append(t)
+            descs[i].name = name.encode()
+            descs[i].data = C.cast(t.data_ptr(), C.POINTER(C.c_float))
+            descs[i].numel = t.numel()
+        _lib.check(lib.r50_load_weights(self._handle, descs, len(named)), self._handle, "r50_load_weights")
+        if self._micro_batch:
+            self.set_option("micro_batch", self._micro_batch)
+        return self
+
+    def cuda(self, device=None) -> "ResNet50Backbone":
+        return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
+
+    def eval(self) -> "ResNet50Backbone":
+        self.training = False      # BN always uses running statistics (folded at load time)
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise _lib.R50Error("ResNet50Backbone is inference-only (the reference calls .eval(), :209)")
+        return self
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        return self.features(x).view(x.shape[0], FEATURE_DIM, 1, 1)
+
+    forward = __call__
+
+    # ---- feature path -----------------------------------------------------------------------
+    def _check_input(self, x: torch.Tensor) -> torch.Tensor:
+        if self._handle is None:
+            raise _lib.R50Error("call .to('cuda:N') before running the backbone")
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 224, 224):
+            raise ValueError(f"expected (N,3,224,224) frames, got {tuple(x.shape)}")
+        if x.device != self._device:
+            raise ValueError(f"frames are on {x.device}, backbone on {self._device}")
+        if x.dtype != torch.float32:
+            x = x.to(torch.float32)
+        return x.contiguous()
+
+    def features(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(N,3,224,224) fp32 NCHW on the backbone's device -> (N,2048) fp32 (= backbone(x).flatten(1))."""
+        x = self._check_input(x)
+        n = x.shape[0]
+        if out is None:
+            out = torch.empty((n, FEATURE_DIM), dtype=torch.float32, device=self._device)
+        elif out.shape != (n, FEATURE_DIM) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self._device:
+            raise ValueError("out must be a contiguous fp32 (N,2048) tensor on the backbone's device")
+        if n == 0:
+            return out
+        lib = _lib.load_library()
+        stream = torch.cuda.current_stream(self._device).cuda_stream
+        _lib.check(lib.r50_forward(self._handle, x.data_ptr(), n, out.data_ptr(), stream), self._handle, "r50_forward")
+        return out
+
+    def layer(self, x: torch.Tensor, name: str) -> torch.Tensor:
+        """Debug hook: named intermediate activation as a bf16 NHWC tensor (per-layer parity tests)."""
+        x = self._check_input(x)
+        n = x.shape[0]
+        lib = _lib.load_library()
+        cap = n * 112 * 112 * 64
+        buf = torch.empty(cap, dtype=torch.bfloat16, device=self._device)
+        dims = (C.c_int64 * 4)()
+        stream = torch.cuda.current_stream(self._device).cuda_stream
+        _lib.check(lib.r50_forward_layer(self._handle, x.data_ptr(), n, name.encode(), buf.data_ptr(), cap * 2, dims, stream),
+                   self._handle, "r50_forward_layer")
+        d = [int(v) for v in dims]
+        return buf[: d[0] * d[1] * d[2] * d[3]].view(*d)
+
+    # ---- options / profiling ----------------------------------------------------------------
+    def set_option(self, key: str, value: int) -> None:
+        _lib.check(_lib.load_library().r50_set_option(self._handle, key.encode(), int(value)), self._handle, "r50_set_option")
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64()
+        _lib.check(_lib.load_library().r50_get_option(self._handle, key.encode(), C.byref(v)), self._handle, "r50_get_option")
+        return int(v.value)
+
+    def profile_reset(self) -> None:
+        _lib.check(_lib.load_library().r50_profile_reset(self._handle), self._handle, "r50_profile_reset")
+
+    def profile_collect(self) -> Dict[str, Dict[str, float]]:
+        lib = _lib.load_library()
+        _lib.check(lib.r50_profile_collect(self._handle), self._handle, "r50_profile_collect")
+        out = {}
+        for i in range(lib.r50_profile_count(self._handle)):
+            name = C.c_char_p(); launches = C.c_int64(); ms = C.c_double(); fl = C.c_double(); by = C.c_double()
+            _lib.check(lib.r50_profile_entry(self._handle, i, C.byref(name), C.byref(launches), C.byref(ms),
+                                             C.byref(fl), C.byref(by)), self._handle, "r50_profile_entry")
+            out[name.value.decode()] = {"launches": int(launches.value), "ms": float(ms.value),
+                                        "flops": float(fl.value), "bytes": float(by.value)}
+        return out
+
+    # ---- lifetime ---------------------------------------------------------------------------
+    def _release(self) -> None:
+        if self._handle is not None:
+            _lib.load_library().r50_destroy(self._handle)
+            self._handle = None
+
+    def close(self) -> None:
+        self._release()
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass

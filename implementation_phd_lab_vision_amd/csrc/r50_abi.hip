@@ -1,0 +1,612 @@
+// Host side of libr50hip.so: C ABI declared in include/r50.h.
+// Builds the static ResNet-50 [:-1] schedule (upstream torchvision models/resnet.py, the module
+// list the reference cuts at src/preprocess_resnet_features.py:207-209), folds BN, packs weights
+// and launches the gfx950 kernels of kernels.h.
+#include "kernels.h"
+#include "../../include/r50.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;   // errors raised without a handle (r50_create, r50_op_*)
+
+struct Prof {
+    const char* name;
+    int64_t launches = 0;
+    double ms = 0, flops = 0, bytes = 0;
+};
+enum ProfClass { PC_IGEMM = 0, PC_STEM_CONV, PC_MAXPOOL, PC_AVGPOOL, PC_STEM_PACK, PC_COUNT };
+const char* kProfNames[PC_COUNT] = {"igemm", "conv1", "maxpool", "avgpool", "stem_pack"};
+
+struct EvRec {
+    hipEvent_t a, b;
+    int cls;
+    double flops, bytes;
+};
+
+struct ConvLayer {
+    std::string conv_key, bn_key;
+    int cin, cout, ks, stride, pad;
+    __bf16* w = nullptr;    // device, (cout, ks, ks, cin)
+    float* bias = nullptr;  // device
+};
+
+}  // namespace
+
+struct r50_handle {
+    int device = 0;
+    int precision = R50_PREC_BF16;
+    int max_batch = 0;
+    int micro_batch = 0;
+    int profile = 0;
+    int tile_override = 0;
+    bool loaded = false;
+    std::string err;
+    std::vector<ConvLayer> convs;       // execution order, convs[0] = stem
+    char* stem_w = nullptr;             // packed stem weights (device)
+    char* stem_xp = nullptr;            // packed input image (device)
+    __bf16* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    void* zero = nullptr;
+    size_t buf_bytes = 0;
+    Prof prof[PC_COUNT];
+    std::vector<EvRec> ev_pending;
+    std::vector<hipEvent_t> ev_free;
+};
+
+namespace {
+
+int fail(r50_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(h, R50_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+constexpr int kStages[4][3] = {{64, 3, 1}, {128, 4, 2}, {256, 6, 2}, {512, 3, 2}};
+constexpr float kBnEps = 1e-5f;
+
+std::vector<ConvLayer> make_specs() {
+    std::vector<ConvLayer> v;
+    auto add = [&](const std::string& c, const std::string& b, int cin, int cout, int ks, int s, int p) {
+        ConvLayer L;
+        L.conv_key = c; L.bn_key = b; L.cin = cin; L.cout = cout; L.ks = ks; L.stride = s; L.pad = p;
+        v.push_back(L);
+    };
+    add("conv1", "bn1", 3, 64, 7, 2, 3);
+    int inpl = 64;
+    for (int si = 0; si < 4; ++si) {
+        const int planes = kStages[si][0], blocks = kStages[si][1], stride = kStages[si][2];
+        for (int b = 0; b < blocks; ++b) {
+            const int s = (b == 0) ? stride : 1;
+            const std::string p = "layer" + std::to_string(si + 1) + "." + std::to_string(b);
+            add(p + ".conv1", p + ".bn1", inpl, planes, 1, 1, 0);
+            add(p + ".conv2", p + ".bn2", planes, planes, 3, s, 1);
+            add(p + ".conv3", p + ".bn3", planes, planes * 4, 1, 1, 0);
+            if (b == 0) add(p + ".downsample.0", p + ".downsample.1", inpl, planes * 4, 1, s, 0);
+            inpl = planes * 4;
+        }
+    }
+    return v;
+}
+
+// BN fold in fp32, op order fixed (no contraction: built with -ffp-contract=off):
+//   scale = gamma / sqrt(var + eps);  w' = w * scale;  b' = beta - mean * scale
+void fold_bn(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+             int cout, int per_out, std::vector<float>& wf, std::vector<float>& bf) {
+    wf.resize((size_t)cout * per_out);
+    bf.resize(cout);
+    for (int o = 0; o < cout; ++o) {
+        const float ve = var[o] + kBnEps;
+        const float sd = std::sqrt(ve);
+        const float scale = gamma[o] / sd;
+        for (int i = 0; i < per_out; ++i) wf[(size_t)o * per_out + i] = w[(size_t)o * per_out + i] * scale;
+        const float ms = mean[o] * scale;
+        bf[o] = beta[o] - ms;
+    }
+}
+
+// (cout, cin, k, k) fp32 -> (cout, k, k, cin) bf16
+void pack_ohwi_bf16(const float* wf, int cout, int cin, int ks, std::vector<uint16_t>& out) {
+    out.resize((size_t)cout * ks * ks * cin);
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < ks * ks; ++t)
+                out[((size_t)o * ks * ks + t) * cin + c] = f32_to_bf16_rne(wf[((size_t)o * cin + c) * ks * ks + t]);
+}
+
+inline int perm_row_to_cout(int rho) {   // LDS/MFMA row -> channel inside a 32-row group (kernels.h)
+    return (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+}
+
+// stem: (64,3,7,7) fp32 folded -> [kh][rho][j=0..7][c=0..3] bf16, j = kw + 1, zero elsewhere
+void pack_stem(const float* wf, std::vector<uint16_t>& out) {
+    out.assign((size_t)7 * 64 * 32, 0);
+    for (int kh = 0; kh < 7; ++kh)
+        for (int rho = 0; rho < 64; ++rho) {
+            const int o = perm_row_to_cout(rho);
+            for (int kw = 0; kw < 7; ++kw)
+                for (int c = 0; c < 3; ++c)
+                    out[(((size_t)kh * 64 + rho) * 8 + (kw + 1)) * 4 + c] =
+                        f32_to_bf16_rne(wf[(((size_t)o * 3 + c) * 7 + kh) * 7 + kw]);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------------------------
+struct TileCfg { int id, bc, bp; };
+// id: 1 = 128c x 128p, 2 = 64c x 128p, 3 = 64c x 256p, 4 = 256c x 128p, 5 = 128c x 64p;
+// +16 = register staging instead of LDS-DMA.
+constexpr int kRegStageBit = 16;
+
+template <int BC, int BP, int WC, int WP, bool G>
+hipError_t launch_igemm_t(ConvArgs a, hipStream_t s) {
+    a.n_ctiles = a.Cout / BC;
+    a.n_blocks = a.n_ctiles * ((a.M + BP - 1) / BP);
+    constexpr size_t lds = 2 * (BC + BP) * 128;
+    auto kern = igemm_bf16_kernel<BC, BP, WC, WP, G>;
+    if (lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+int auto_tile(int cout, int M) {
+    if (cout % 128) return (M >= 256 * 512) ? 3 : 2;
+    if (M < 128 * 96) return 5;   // few pixel tiles: halve BP to fill the CUs
+    return 1;
+}
+
+hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s) {
+    if (tile == 0) tile = auto_tile(a.Cout, a.M);
+    const bool glds = !(tile & kRegStageBit);
+    const int id = tile & (kRegStageBit - 1);
+#define R50_DISPATCH(BC, BP, WC, WP)                                                      \
+    return glds ? launch_igemm_t<BC, BP, WC, WP, true>(a, s) : launch_igemm_t<BC, BP, WC, WP, false>(a, s)
+    switch (id) {
+        case 1: if (a.Cout % 128) return hipErrorInvalidValue; R50_DISPATCH(128, 128, 2, 2);
+        case 2: R50_DISPATCH(64, 128, 1, 4);
+        case 3: R50_DISPATCH(64, 256, 1, 4);
+        case 4: if (a.Cout % 256) return hipErrorInvalidValue; R50_DISPATCH(256, 128, 4, 1);
+        case 5: if (a.Cout % 128) return hipErrorInvalidValue; R50_DISPATCH(128, 64, 2, 2);
+        default: return hipErrorInvalidValue;
+    }
+#undef R50_DISPATCH
+}
+
+int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, const void* wt, const float* bias,
+                   const void* res, void* y, int cout, int ks, int stride, int pad, int relu, const void* zero) {
+    if (!x || !wt || !bias || !y || !zero) return R50_ERR_INVALID;
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cin % 64 || cout <= 0 || cout % 64) return R50_ERR_INVALID;
+    if (!(ks == 1 || ks == 3) || stride < 1 || pad < 0 || pad >= ks) return R50_ERR_INVALID;
+    a.x = (const __bf16*)x; a.w = (const __bf16*)wt; a.bias = bias; a.res = (const __bf16*)res; a.y = (__bf16*)y;
+    a.zero = zero;
+    a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;
+    a.Ho = (h + 2 * pad - ks) / stride + 1;
+    a.Wo = (w + 2 * pad - ks) / stride + 1;
+    if (a.Ho <= 0 || a.Wo <= 0) return R50_ERR_INVALID;
+    a.ks = ks; a.stride = stride; a.pad = pad; a.relu = relu;
+    const long long M = (long long)n * a.Ho * a.Wo;
+    // 32-bit index budget of the kernel: byte offsets of x / y stay below 2^32 elements*2
+    if (M > (1ll << 30) || (long long)n * h * w * cin > (1ll << 31) - 1 || M * cout > (1ll << 31) - 1)
+        return R50_ERR_INVALID;
+    a.M = (int)M; a.HoWo = a.Ho * a.Wo;
+    a.cin_chunks = cin / 64; a.nk = ks * ks * a.cin_chunks; a.Ktot = ks * ks * cin;
+    a.n_ctiles = 0; a.n_blocks = 0;
+    return R50_OK;
+}
+
+// profiling brackets
+void prof_begin(r50_handle* h, hipStream_t s, EvRec& r, int cls, double flops, double bytes) {
+    if (!h || !h->profile) return;
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!h->ev_free.empty()) { e = h->ev_free.back(); h->ev_free.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    r.a = get(); r.b = get(); r.cls = cls; r.flops = flops; r.bytes = bytes;
+    (void)hipEventRecord(r.a, s);
+}
+void prof_end(r50_handle* h, hipStream_t s, EvRec& r) {
+    if (!h || !h->profile) return;
+    (void)hipEventRecord(r.b, s);
+    h->ev_pending.push_back(r);
+}
+
+int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, int ww, const __bf16* res,
+             __bf16* y, int relu, hipStream_t s, int* ho, int* wo) {
+    ConvArgs a;
+    int rc = fill_conv_args(a, x, n, hh, ww, L.cin, L.w, L.bias, res, y, L.cout, L.ks, L.stride, L.pad, relu, h->zero);
+    if (rc) return fail(h, rc, "conv args invalid for " + L.conv_key);
+    EvRec r{};
+    const double flops = 2.0 * a.M * (double)a.Cout * a.Ktot;
+    const double bytes = 2.0 * ((double)n * hh * ww * L.cin + (double)a.M * a.Cout * (res ? 2 : 1) + (double)a.Cout * a.Ktot);
+    prof_begin(h, s, r, PC_IGEMM, flops, bytes);
+    hipError_t e = launch_igemm(a, h->tile_override, s);
+    prof_end(h, s, r);
+    if (e != hipSuccess) return fail(h, R50_ERR_HIP, "igemm launch (" + L.conv_key + "): " + hipGetErrorString(e));
+    *ho = a.Ho; *wo = a.Wo;
+    return R50_OK;
+}
+
+hipError_t launch_stem_pack(const float* x, void* xp, int n, hipStream_t s) {
+    const long long total = (long long)n * STEM_HP * STEM_WP;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(stem_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (u32x2*)xp, n);
+    return hipGetLastError();
+}
+hipError_t launch_stem_conv(const void* xp, const void* wpk, const float* bias, void* y, int n, hipStream_t s) {
+    hipLaunchKernelGGL(stem_conv_kernel, dim3(n * (112 / STEM_ROWS_PER_WG)), dim3(256), STEM_LDS_BYTES, s,
+                       (const char*)xp, (const char*)wpk, bias, (__bf16*)y);
+    return hipGetLastError();
+}
+hipError_t launch_maxpool(const void* x, void* y, int n, int h, int w, int c, hipStream_t s) {
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)n * ho * wo * (c / 8);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)x, (__bf16*)y,
+                       n, h, w, c, ho, wo);
+    return hipGetLastError();
+}
+hipError_t launch_avgpool(const void* x, float* y, int n, int hw, int c, hipStream_t s) {
+    const int total = n * (c / 8);
+    hipLaunchKernelGGL(avgpool_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const __bf16*)x, y, n, hw, c,
+                       1.0f / (float)hw);
+    return hipGetLastError();
+}
+
+// Runs `n` frames (n <= max_batch) through the stack.  If `tap` is non-null, stops once the named
+// activation is available and reports it through tap_ptr / dims.
+int run_stack(r50_handle* h, const float* x, int n, float* out, hipStream_t s, const char* tap,
+              const __bf16** tap_ptr, int64_t dims[4]) {
+    auto hit = [&](const std::string& name, const __bf16* p, int hh, int ww, int c) {
+        if (tap && name == tap) {
+            *tap_ptr = p; dims[0] = n; dims[1] = hh; dims[2] = ww; dims[3] = c;
+            return true;
+        }
+        return false;
+    };
+    EvRec r{};
+    prof_begin(h, s, r, PC_STEM_PACK, 0, (double)n * (3.0 * 224 * 224 * 4 + (double)STEM_HP * STEM_WP * 8));
+    hipError_t e = launch_stem_pack(x, h->stem_xp, n, s);
+    prof_end(h, s, r);
+    if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem_pack: ") + hipGetErrorString(e));
+
+    prof_begin(h, s, r, PC_STEM_CONV, 2.0 * n * 112 * 112 * 64 * 147.0,
+               (double)n * ((double)STEM_HP * STEM_WP * 8 + 112.0 * 112 * 64 * 2));
+    e = launch_stem_conv(h->stem_xp, h->stem_w, h->convs[0].bias, h->buf[0], n, s);
+    prof_end(h, s, r);
+    if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem_conv: ") + hipGetErrorString(e));
+    if (hit("stem", h->buf[0], 112, 112, 64)) return R50_OK;
+
+    prof_begin(h, s, r, PC_MAXPOOL, 0, (double)n * (112.0 * 112 + 56.0 * 56) * 64 * 2);
+    e = launch_maxpool(h->buf[0], h->buf[1], n, 112, 112, 64, s);
+    prof_end(h, s, r);
+    if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("maxpool: ") + hipGetErrorString(e));
+    if (hit("pool", h->buf[1], 56, 56, 64)) return R50_OK;
+
+    int cur = 1, hh = 56, ww = 56;
+    size_t li = 1;
+    for (int si = 0; si < 4; ++si) {
+        const int blocks = kStages[si][1];
+        for (int b = 0; b < blocks; ++b) {
+            int fr[4], nf = 0;
+            for (int i = 0; i < 5; ++i)
+                if (i != cur) fr[nf++] = i;
+            const std::string p = "layer" + std::to_string(si + 1) + "." + std::to_string(b);
+            const ConvLayer& c1 = h->convs[li];
+            const ConvLayer& c2 = h->convs[li + 1];
+            const ConvLayer& c3 = h->convs[li + 2];
+            int h1, w1, h2, w2, h3, w3;
+            int rc = run_conv(h, c1, h->buf[cur], n, hh, ww, nullptr, h->buf[fr[0]], 1, s, &h1, &w1);
+            if (rc) return rc;
+            if (hit(p + ".t1", h->buf[fr[0]], h1, w1, c1.cout)) return R50_OK;
+            rc = run_conv(h, c2, h->buf[fr[0]], n, h1, w1, nullptr, h->buf[fr[1]], 1, s, &h2, &w2);
+            if (rc) return rc;
+            if (hit(p + ".t2", h->buf[fr[1]], h2, w2, c2.cout)) return R50_OK;
+            const __bf16* idn = h->buf[cur];
+            if (b == 0) {
+                const ConvLayer& cd = h->convs[li + 3];
+                int hd, wd;
+                rc = run_conv(h, cd, h->buf[cur], n, hh, ww, nullptr, h->buf[fr[2]], 0, s, &hd, &wd);
+                if (rc) return rc;
+                if (hit(p + ".ds", h->buf[fr[2]], hd, wd, cd.cout)) return R50_OK;
+                idn = h->buf[fr[2]];
+            }
+            rc = run_conv(h, c3, h->buf[fr[1]], n, h2, w2, idn, h->buf[fr[3]], 1, s, &h3, &w3);
+            if (rc) return rc;
+            cur = fr[3]; hh = h3; ww = w3;
+            if (hit(p, h->buf[cur], hh, ww, c3.cout)) return R50_OK;
+            li += (b == 0) ? 4 : 3;
+        }
+    }
+    if (tap) return fail(h, R50_ERR_INVALID, std::string("unknown layer name: ") + tap);
+    prof_begin(h, s, r, PC_AVGPOOL, 0, (double)n * (hh * ww * 2048.0 * 2 + 2048.0 * 4));
+    e = launch_avgpool(h->buf[cur], out, n, hh * ww, 2048, s);
+    prof_end(h, s, r);
+    if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("avgpool: ") + hipGetErrorString(e));
+    return R50_OK;
+}
+
+void free_all(r50_handle* h) {
+    for (auto& L : h->convs) {
+        if (L.w) (void)hipFree(L.w);
+        if (L.bias) (void)hipFree(L.bias);
+        L.w = nullptr; L.bias = nullptr;
+    }
+    if (h->stem_w) (void)hipFree(h->stem_w);
+    if (h->stem_xp) (void)hipFree(h->stem_xp);
+    for (auto& b : h->buf) { if (b) (void)hipFree(b); b = nullptr; }
+    if (h->zero) (void)hipFree(h->zero);
+    for (auto& r : h->ev_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& e : h->ev_free) (void)hipEventDestroy(e);
+    h->ev_pending.clear(); h->ev_free.clear();
+}
+
+// process-wide zero page for the op-level entry points
+void* g_zero_page[16] = {nullptr};
+int get_zero_page(void** out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return R50_ERR_HIP;
+    if (!g_zero_page[dev]) {
+        if (hipMalloc(&g_zero_page[dev], 256) != hipSuccess) return R50_ERR_NOMEM;
+        if (hipMemset(g_zero_page[dev], 0, 256) != hipSuccess) return R50_ERR_HIP;
+    }
+    *out = g_zero_page[dev];
+    return R50_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* r50_version(void) { return "r50hip 0.1.0 (gfx950)"; }
+
+const char* r50_last_error(r50_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int r50_create(r50_handle** out, int device_id, int precision, int max_batch) {
+    if (!out) return fail(nullptr, R50_ERR_INVALID, "r50_create: out is null");
+    *out = nullptr;
+    if (precision != R50_PREC_BF16) return fail(nullptr, R50_ERR_INVALID, "r50_create: unsupported precision");
+    if (max_batch < 1 || max_batch > 1024) return fail(nullptr, R50_ERR_INVALID, "r50_create: max_batch must be in [1,1024]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, R50_ERR_HIP, "r50_create: no HIP device available");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, R50_ERR_INVALID, "r50_create: bad device_id");
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_id));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, R50_ERR_HIP, std::string("r50_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    r50_handle* h = new r50_handle();
+    h->device = device_id; h->precision = precision; h->max_batch = max_batch;
+    h->convs = make_specs();
+    for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = kProfNames[i];
+    h->buf_bytes = (size_t)max_batch * 112 * 112 * 64 * 2;
+    bool ok = true;
+    for (int i = 0; i < 5 && ok; ++i) ok = hipMalloc((void**)&h->buf[i], h->buf_bytes) == hipSuccess;
+    ok = ok && hipMalloc((void**)&h->stem_xp, (size_t)max_batch * STEM_HP * STEM_WP * 8) == hipSuccess;
+    ok = ok && hipMalloc((void**)&h->stem_w, STEM_W_BYTES) == hipSuccess;
+    ok = ok && hipMalloc(&h->zero, 256) == hipSuccess && hipMemset(h->zero, 0, 256) == hipSuccess;
+    if (!ok) {
+        free_all(h);
+        delete h;
+        return fail(nullptr, R50_ERR_NOMEM, "r50_create: device allocation failed");
+    }
+    *out = h;
+    return R50_OK;
+}
+
+void r50_destroy(r50_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    free_all(h);
+    delete h;
+}
+
+int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensors) {
+    if (!h) return fail(nullptr, R50_ERR_INVALID, "r50_load_weights: null handle");
+    if (!tensors || n_tensors <= 0) return fail(h, R50_ERR_INVALID, "r50_load_weights: no tensors");
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::map<std::string, const r50_tensor_desc*> by_name;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!tensors[i].name || !tensors[i].data) return fail(h, R50_ERR_INVALID, "r50_load_weights: null name/data");
+        by_name[tensors[i].name] = &tensors[i];
+    }
+    auto need = [&](const std::string& k, int64_t numel, const float** p) -> int {
+        auto it = by_name.find(k);
+        if (it == by_name.end()) return fail(h, R50_ERR_INVALID, "r50_load_weights: missing tensor " + k);
+        if (it->second->numel != numel)
+            return fail(h, R50_ERR_INVALID, "r50_load_weights: tensor " + k + " has " + std::to_string(it->second->numel) +
+                                                " elements, expected " + std::to_string(numel));
+        *p = it->second->data;
+        return R50_OK;
+    };
+    std::vector<float> wf, bf;
+    std::vector<uint16_t> pk;
+    for (size_t i = 0; i < h->convs.size(); ++i) {
+        ConvLayer& L = h->convs[i];
+        const float *w, *g, *b, *m, *v;
+        const int per_out = L.cin * L.ks * L.ks;
+        int rc;
+        if ((rc = need(L.conv_key + ".weight", (int64_t)L.cout * per_out, &w))) return rc;
+        if ((rc = need(L.bn_key + ".weight", L.cout, &g))) return rc;
+        if ((rc = need(L.bn_key + ".bias", L.cout, &b))) return rc;
+        if ((rc = need(L.bn_key + ".running_mean", L.cout, &m))) return rc;
+        if ((rc = need(L.bn_key + ".running_var", L.cout, &v))) return rc;
+        fold_bn(w, g, b, m, v, L.cout, per_out, wf, bf);
+        if (!L.bias) HIP_TRY(h, hipMalloc((void**)&L.bias, L.cout * sizeof(float)));
+        HIP_TRY(h, hipMemcpy(L.bias, bf.data(), L.cout * sizeof(float), hipMemcpyHostToDevice));
+        if (i == 0) {
+            pack_stem(wf.data(), pk);
+            HIP_TRY(h, hipMemcpy(h->stem_w, pk.data(), STEM_W_BYTES, hipMemcpyHostToDevice));
+        } else {
+            pack_ohwi_bf16(wf.data(), L.cout, L.cin, L.ks, pk);
+            if (!L.w) HIP_TRY(h, hipMalloc((void**)&L.w, pk.size() * 2));
+            HIP_TRY(h, hipMemcpy(L.w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+        }
+    }
+    h->loaded = true;
+    return R50_OK;
+}
+
+int r50_forward(r50_handle* h, const float* x, int n, float* out, void* stream) {
+    if (!h) return fail(nullptr, R50_ERR_INVALID, "r50_forward: null handle");
+    if (!h->loaded) return fail(h, R50_ERR_STATE, "r50_forward: weights not loaded");
+    if (!x || !out) return fail(h, R50_ERR_INVALID, "r50_forward: null buffer");
+    if (n < 0) return fail(h, R50_ERR_INVALID, "r50_forward: n < 0");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int chunk = h->max_batch;
+    if (h->micro_batch > 0 && h->micro_batch < chunk) chunk = h->micro_batch;
+    for (int i = 0; i < n; i += chunk) {
+        const int m = (n - i < chunk) ? (n - i) : chunk;
+        int rc = run_stack(h, x + (size_t)i * 3 * 224 * 224, m, out + (size_t)i * 2048, (hipStream_t)stream,
+                           nullptr, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    return R50_OK;
+}
+
+int r50_forward_layer(r50_handle* h, const float* x, int n, const char* layer, void* out, int64_t cap,
+                      int64_t dims_out[4], void* stream) {
+    if (!h) return fail(nullptr, R50_ERR_INVALID, "r50_forward_layer: null handle");
+    if (!h->loaded) return fail(h, R50_ERR_STATE, "r50_forward_layer: weights not loaded");
+    if (!x || !out || !layer || !dims_out) return fail(h, R50_ERR_INVALID, "r50_forward_layer: null argument");
+    if (n < 1 || n > h->max_batch) return fail(h, R50_ERR_INVALID, "r50_forward_layer: n must be in [1,max_batch]");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const __bf16* p = nullptr;
+    int rc = run_stack(h, x, n, nullptr, (hipStream_t)stream, layer, &p, dims_out);
+    if (rc) return rc;
+    const int64_t bytes = dims_out[0] * dims_out[1] * dims_out[2] * dims_out[3] * 2;
+    if (bytes > cap) return fail(h, R50_ERR_INVALID, "r50_forward_layer: output buffer too small");
+    HIP_TRY(h, hipMemcpyAsync(out, p, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return R50_OK;
+}
+
+int r50_set_option(r50_handle* h, const char* key, int64_t value) {
+    if (!h || !key) return fail(h, R50_ERR_INVALID, "r50_set_option: null argument");
+    const std::string k(key);
+    if (k == "micro_batch") { if (value < 0) return fail(h, R50_ERR_INVALID, "micro_batch < 0"); h->micro_batch = (int)value; }
+    else if (k == "profile") h->profile = value ? 1 : 0;
+    else if (k == "tile") h->tile_override = (int)value;
+    else return fail(h, R50_ERR_INVALID, "r50_set_option: unknown key " + k);
+    return R50_OK;
+}
+
+int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
+    if (!h || !key || !value) return fail(h, R50_ERR_INVALID, "r50_get_option: null argument");
+    const std::string k(key);
+    if (k == "micro_batch") *value = h->micro_batch;
+    else if (k == "profile") *value = h->profile;
+    else if (k == "tile") *value = h->tile_override;
+    else if (k == "max_batch") *value = h->max_batch;
+    else if (k == "workspace_bytes") *value = (int64_t)(5 * h->buf_bytes + (size_t)h->max_batch * STEM_HP * STEM_WP * 8);
+    else return fail(h, R50_ERR_INVALID, "r50_get_option: unknown key " + k);
+    return R50_OK;
+}
+
+int r50_profile_reset(r50_handle* h) {
+    if (!h) return R50_ERR_INVALID;
+    for (auto& r : h->ev_pending) { h->ev_free.push_back(r.a); h->ev_free.push_back(r.b); }
+    h->ev_pending.clear();
+    for (int i = 0; i < PC_COUNT; ++i) { h->prof[i].launches = 0; h->prof[i].ms = h->prof[i].flops = h->prof[i].bytes = 0; }
+    return R50_OK;
+}
+
+int r50_profile_collect(r50_handle* h) {
+    if (!h) return R50_ERR_INVALID;
+    for (auto& r : h->ev_pending) {
+        HIP_TRY(h, hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, r.a, r.b));
+        Prof& p = h->prof[r.cls];
+        p.launches += 1; p.ms += ms; p.flops += r.flops; p.bytes += r.bytes;
+        h->ev_free.push_back(r.a); h->ev_free.push_back(r.b);
+    }
+    h->ev_pending.clear();
+    return R50_OK;
+}
+
+int r50_profile_count(r50_handle* h) { return h ? PC_COUNT : 0; }
+
+int r50_profile_entry(r50_handle* h, int i, const char** name, int64_t* launches, double* total_ms, double* flops,
+                      double* bytes) {
+    if (!h || i < 0 || i >= PC_COUNT) return R50_ERR_INVALID;
+    if (name) *name = h->prof[i].name;
+    if (launches) *launches = h->prof[i].launches;
+    if (total_ms) *total_ms = h->prof[i].ms;
+    if (flops) *flops = h->prof[i].flops;
+    if (bytes) *bytes = h->prof[i].bytes;
+    return R50_OK;
+}
+
+// ---- op-level entry points -------------------------------------------------------------------
+int r50_op_conv2d(const void* x, int n, int h, int w, int cin, const void* wt, const float* bias, const void* res,
+                  void* y, int cout, int ksize, int stride, int pad, int relu, int tile, void* stream) {
+    void* zero = nullptr;
+    int rc = get_zero_page(&zero);
+    if (rc) return fail(nullptr, rc, "r50_op_conv2d: zero page allocation failed");
+    ConvArgs a;
+    rc = fill_conv_args(a, x, n, h, w, cin, wt, bias, res, y, cout, ksize, stride, pad, relu, zero);
+    if (rc) return fail(nullptr, rc, "r50_op_conv2d: invalid arguments");
+    hipError_t e = launch_igemm(a, tile, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(nullptr, R50_ERR_HIP, std::string("r50_op_conv2d: ") + hipGetErrorString(e));
+    return R50_OK;
+}
+
+int64_t r50_stem_scratch_bytes(int n) { return (int64_t)STEM_W_BYTES + (int64_t)n * STEM_HP * STEM_WP * 8; }
+
+int r50_op_stem(const float* x, int n, const float* w_host, const float* bias_dev, void* scratch, void* y, void* stream) {
+    if (!x || !w_host || !bias_dev || !scratch || !y || n < 1) return fail(nullptr, R50_ERR_INVALID, "r50_op_stem: invalid arguments");
+    std::vector<uint16_t> pk;
+    pack_stem(w_host, pk);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(nullptr, hipMemcpyAsync(scratch, pk.data(), STEM_W_BYTES, hipMemcpyHostToDevice, s));
+    HIP_TRY(nullptr, hipStreamSynchronize(s));   // pk is a host temporary
+    char* xp = (char*)scratch + STEM_W_BYTES;
+    HIP_TRY(nullptr, launch_stem_pack(x, xp, n, s));
+    HIP_TRY(nullptr, launch_stem_conv(xp, scratch, bias_dev, y, n, s));
+    return R50_OK;
+}
+
+int r50_op_maxpool(const void* x, int n, int h, int w, int c, void* y, void* stream) {
+    if (!x || !y || n < 1 || h < 1 || w < 1 || c < 8 || c % 8) return fail(nullptr, R50_ERR_INVALID, "r50_op_maxpool: invalid arguments");
+    HIP_TRY(nullptr, launch_maxpool(x, y, n, h, w, c, (hipStream_t)stream));
+    return R50_OK;
+}
+
+int r50_op_avgpool(const void* x, int n, int hw, int c, float* y, void* stream) {
+    if (!x || !y || n < 1 || hw < 1 || c < 8 || c % 8) return fail(nullptr, R50_ERR_INVALID, "r50_op_avgpool: invalid arguments");
+    HIP_TRY(nullptr, launch_avgpool(x, y, n, hw, c, (hipStream_t)stream));
+    return R50_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+"""Thin wrappers over the op-level C-ABI entry points (``r50_op_*`` in include/r50.h).
+
+Each mirrors one module of the reference's ``nn.Sequential`` (upstream torchvision
+``models/resnet.py``): Conv2d(+folded BatchNorm2d)(+residual)(+ReLU), MaxPool2d(3,2,1),
+AdaptiveAvgPool2d((1,1)).  Tensors are bf16 NHWC on an MI355X; used by the per-kernel parity tests.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+# tile-config ids of the implicit-GEMM kernel (DESIGN.md "Kernels"); +REG_STAGE = register staging
+TILE_AUTO = 0
+TILE_128x128 = 1
+TILE_64x128 = 2
+TILE_64x256 = 3
+TILE_256x128 = 4
+TILE_128x64 = 5
+REG_STAGE = 16
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need(t: torch.Tensor, dtype, name: str) -> None:
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"{name}: need a contiguous {dtype} tensor on the GPU")
+
+
+def conv2d_bf16(x: torch.Tensor, w_ohwi: torch.Tensor, bias: torch.Tensor, stride: int = 1, pad: int = 0,
+                relu: bool = True, residual: Optional[torch.Tensor] = None, tile: int = TILE_AUTO) -> torch.Tensor:
+    """x (N,H,W,Cin) bf16, w_ohwi (Cout,k,k,Cin) bf16, bias (Cout) fp32 -> (N,Ho,Wo,Cout) bf16."""
+    _need(x, torch.bfloat16, "x"); _need(w_ohwi, torch.bfloat16, "w"); _need(bias, torch.float32, "bias")
+    n, h, w, cin = x.shape
+    cout, k, k2, cin2 = w_ohwi.shape
+    if k != k2 or cin2 != cin or bias.numel() != cout:
+        raise ValueError("conv2d_bf16: inconsistent shapes")
+    ho = (h + 2 * pad - k) // stride + 1
+    wo = (w + 2 * pad - k) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=x.device)
+    if residual is not None:
+        _need(residual, torch.bfloat16, "residual")
+        if residual.shape != y.shape:
+            raise ValueError("conv2d_bf16: residual shape mismatch")
+    lib = _lib.load_library()
+    with torch.cuda.device(x.device):
+        rc = lib.r50_op_conv2d(x.data_ptr(), n, h, w, cin, w_ohwi.data_ptr(), bias.data_ptr(),
+                               residual.data_ptr() if residual is not None else None, y.data_ptr(),
+                               cout, k, stride, pad, int(relu), int(tile), _stream(x))
+    _lib.check(rc, None, "r50_op_conv2d")
+    return y
+
+
+def stem_bf16(x_nchw: torch.Tensor, w_folded_oihw: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """conv1 7x7 s2 p3 + folded bn1 + ReLU: (N,3,224,224) fp32 NCHW -> (N,112,112,64) bf16 NHWC.
+    ``w_folded_oihw``: (64,3,7,7) fp32 on the HOST (already BN-folded); ``bias``: (64) fp32 on the GPU."""
+    _need(x_nchw, torch.float32, "x"); _need(bias, torch.float32, "bias")
+    if tuple(x_nchw.shape[1:]) != (3, 224, 224) or tuple(w_folded_oihw.shape) != (64, 3, 7, 7):
+        raise ValueError("stem_bf16: bad shapes")
+    w_host = w_folded_oihw.detach().to("cpu", torch.float32).contiguous()
+    n = x_nchw.shape[0]
+    lib = _lib.load_library()
+    scratch = torch.empty(lib.r50_stem_scratch_bytes(n), dtype=torch.uint8, device=x_nchw.device)
+    y = torch.empty((n, 112, 112, 64), dtype=torch.bfloat16, device=x_nchw.device)
+    with torch.cuda.device(x_nchw.device):
+        rc = lib.r50_op_stem(x_nchw.data_ptr(), n, w_host.data_ptr(), bias.data_ptr(), scratch.data_ptr(),
+                             y.data_ptr(), _stream(x_nchw))
+    _lib.check(rc, None, "r50_op_stem")
+    return y
+
+
+def maxpool_bf16(x: torch.Tensor) -> torch.Tensor:
+    """MaxPool2d(3, stride 2, pad 1) on (N,H,W,C) bf16."""
+    _need(x, torch.bfloat16, "x")
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load_library().r50_op_maxpool(x.data_ptr(), n, h, w, c, y.data_ptr(), _stream(x))
+    _lib.check(rc, None, "r50_op_maxpool")
+    return y
+
+
+def avgpool_bf16(x: torch.Tensor) -> torch.Tensor:
+    """AdaptiveAvgPool2d((1,1)) + flatten(1) on (N,H,W,C) bf16 -> (N,C) fp32."""
+    _need(x, torch.bfloat16, "x")
+    n, h, w, c = x.shape
+    y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load_library().r50_op_avgpool(x.data_ptr(), n, h * w, c, y.data_ptr(), _stream(x))
+    _lib.check(rc, None, "r50_op_avgpool")
+    return y

@@ -1,0 +1,122 @@
+/*
+ * r50.h — C ABI of libr50hip.so: MI355X (gfx950) ResNet-50 feature extraction.
+ *
+ * The reference (ferreiraluisa/implementation-phd-lab-vision) has no FFI/plugin registry; its
+ * boundary for this path is a Python call on an nn.Module-like object:
+ *
+ *     backbone = nn.Sequential(*list(resnet50(...).children())[:-1]).to(device).eval()
+ *                                          -- src/preprocess_resnet_features.py:207-209
+ *     feats = backbone(x).flatten(1)       -- src/preprocess_resnet_features.py:242,296
+ *
+ * Each entry point below cites the reference interface it replaces.  Plain pointers and sizes
+ * only: no torch types, no exceptions across the boundary.  Every function returns 0 on success
+ * or a negative r50_status; r50_last_error() gives the text.  One handle per (device, stream);
+ * a handle is not re-entrant.  All device pointers are owned by the caller (e.g. PyTorch
+ * allocations); the handle owns its packed weights and activation workspace.
+ *
+ * Layouts:  frames   fp32 NCHW (n,3,224,224), ImageNet-normalised, contiguous
+ *                    (what src/dataset.py:242-245,429 produces and :295 reshapes)
+ *           features fp32 (n,2048) row-major (= backbone(x).flatten(1), :296)
+ *           internal activations bf16 NHWC.
+ */
+#ifndef R50_H_
+#define R50_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct r50_handle r50_handle;
+
+typedef enum r50_status {
+    R50_OK = 0,
+    R50_ERR_INVALID = -1,   /* bad argument (null pointer, n out of range, unknown name ...) */
+    R50_ERR_HIP = -2,       /* a HIP runtime call failed */
+    R50_ERR_STATE = -3,     /* e.g. forward before weights were loaded */
+    R50_ERR_NOMEM = -4
+} r50_status;
+
+typedef enum r50_precision {
+    R50_PREC_BF16 = 1       /* bf16 operands, fp32 MFMA accumulation (the reference's CUDA autocast
+                               dtype, src/preprocess_resnet_features.py:290-294) */
+} r50_precision;
+
+/* One host tensor handed to r50_load_weights: torchvision state-dict key + fp32 data. */
+typedef struct r50_tensor_desc {
+    const char* name;       /* e.g. "layer1.0.conv1.weight", "bn1.running_var" */
+    const float* data;      /* host pointer, contiguous fp32 (conv weights OIHW) */
+    int64_t numel;
+} r50_tensor_desc;
+
+/* Replaces: backbone construction + .to(device) (preprocess_resnet_features.py:207-209).
+ * Allocates workspace for batches of up to max_batch frames on HIP device `device_id`. */
+int r50_create(r50_handle** out, int device_id, int precision, int max_batch);
+
+/* Replaces: resnet50(weights=IMAGENET1K_V2) state loading + .eval() (:207-209).
+ * Takes every conv weight and BN weight/bias/running_mean/running_var by torchvision key name
+ * (fc.* and num_batches_tracked are not needed), folds eval-mode BN (eps 1e-5) into conv
+ * weight+bias in fp32, converts to bf16 and uploads in the kernels' packed layout.
+ * The caller keeps ownership of the host buffers. */
+int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensors);
+
+/* Replaces: backbone(x).flatten(1) (:242,296).  Asynchronous on `stream` (a hipStream_t; NULL =
+ * default stream).  x_nchw_f32_dev: (n,3,224,224) fp32 on the device; out_f32_dev: (n,2048).
+ * n may exceed max_batch: the call then loops over chunks of max_batch frames. */
+int r50_forward(r50_handle* h, const float* x_nchw_f32_dev, int n, float* out_f32_dev, void* stream);
+
+/* Debug hook for per-layer parity tests (no reference counterpart; equivalent to a forward hook
+ * on the nn.Sequential).  Runs the network on x (n <= max_batch) and copies the named bf16 NHWC
+ * activation into out_bf16_nhwc_dev.  Names: "stem", "pool", "layer{1..4}.{b}",
+ * "layer{i}.{b}.t1", ".t2", ".ds".  dims_out receives {N,H,W,C}. */
+int r50_forward_layer(r50_handle* h, const float* x_nchw_f32_dev, int n, const char* layer,
+                      void* out_bf16_nhwc_dev, int64_t out_capacity_bytes, int64_t dims_out[4],
+                      void* stream);
+
+/* Options: "micro_batch" (frames per pass through the layer stack, 0 = whole batch),
+ * "profile" (1 = bracket every kernel launch with HIP events, see r50_profile_*). */
+int r50_set_option(r50_handle* h, const char* key, int64_t value);
+int r50_get_option(r50_handle* h, const char* key, int64_t* value);
+
+/* Per-kernel timing from HIP events recorded on the launch stream while option "profile" is 1.
+ * r50_profile_collect synchronises the recorded events and accumulates them; then
+ * r50_profile_count / r50_profile_entry enumerate kernel classes ("igemm", "conv1", "maxpool",
+ * "avgpool", "stem_pack") with launch count, total ms, algorithmic flops and bytes. */
+int r50_profile_reset(r50_handle* h);
+int r50_profile_collect(r50_handle* h);
+int r50_profile_count(r50_handle* h);
+int r50_profile_entry(r50_handle* h, int i, const char** name, int64_t* launches, double* total_ms,
+                      double* flops, double* bytes);
+
+const char* r50_last_error(r50_handle* h);   /* h may be NULL: last error of r50_create / r50_op_* */
+void r50_destroy(r50_handle* h);             /* replaces: del backbone */
+const char* r50_version(void);
+
+/* ---- Op-level entry points (per-kernel parity tests; each mirrors one nn.Module of the
+ * reference's Sequential, upstream torchvision models/resnet.py).  bf16 NHWC device buffers. ---- */
+
+/* conv2d(k x k, stride, pad, bias=folded BN) [+ residual] [+ ReLU].  w_ohwi_bf16: (cout,k,k,cin)
+ * bf16; bias fp32 (cout); residual/y: (n,ho,wo,cout) bf16.  cin % 64 == 0, cout % 64 == 0,
+ * k in {1,3}.  tile: 0 = auto, else a tile-config id.  */
+int r50_op_conv2d(const void* x_nhwc_bf16, int n, int h, int w, int cin, const void* w_ohwi_bf16,
+                  const float* bias_f32, const void* residual_nhwc_bf16, void* y_nhwc_bf16,
+                  int cout, int ksize, int stride, int pad, int relu, int tile, void* stream);
+
+/* Stem: fp32 NCHW frames -> conv 7x7 s2 p3 (+folded bn1 bias) + ReLU -> (n,112,112,64) bf16 NHWC.
+ * w_oihw_f32: (64,3,7,7) fp32 *already folded*, host pointer; bias_f32: device pointer (64).
+ * scratch_dev: at least r50_stem_scratch_bytes(n) bytes of device memory. */
+int64_t r50_stem_scratch_bytes(int n);
+int r50_op_stem(const float* x_nchw_f32_dev, int n, const float* w_oihw_f32_host,
+                const float* bias_f32_dev, void* scratch_dev, void* y_nhwc_bf16, void* stream);
+
+/* MaxPool2d(3, stride 2, pad 1) on bf16 NHWC; c % 8 == 0. */
+int r50_op_maxpool(const void* x_nhwc_bf16, int n, int h, int w, int c, void* y_nhwc_bf16, void* stream);
+
+/* AdaptiveAvgPool2d((1,1)) + flatten(1): (n,hw,c) bf16 -> (n,c) fp32; c % 8 == 0. */
+int r50_op_avgpool(const void* x_nhwc_bf16, int n, int hw, int c, float* y_f32, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R50_H_ */

@@ -1,0 +1,149 @@
+"""Per-kernel parity on the MI355X: every HIP kernel, called through the C ABI (r50_op_*), against the
+CPU oracle (oracle/resnet50_oracle.py) on the same seeded bf16 inputs.
+
+Tolerance (stated once, used everywhere below): the device accumulates bf16 x bf16 products in fp32
+(MFMA) where the oracle accumulates in fp64, then both round to bf16.  So outputs must agree to
+within ONE bf16 ulp element-wise (|d| <= 2^-7 * max(|ref|, tiny) ), at most 1 % of elements may
+differ at all, and the tensor rel-L2 must be < 1e-3.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _check_bf16(dev_nhwc: torch.Tensor, ref_nchw: torch.Tensor, what: str):
+    from oracle.resnet50_oracle import rel_l2
+    got = dev_nhwc.float().cpu().permute(0, 3, 1, 2).contiguous()
+    ref = ref_nchw.float()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    diff = (got - ref).abs()
+    ulp = ref.abs().clamp_min(2.0 ** -20) * 2.0 ** -7
+    bad = diff > ulp
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements beyond 1 bf16 ulp, max diff {float(diff.max())}"
+    frac = float((diff > 0).float().mean())
+    assert frac < 0.01, f"{what}: {frac:.4f} of elements differ"
+    r = rel_l2(got, ref)
+    assert r < 1e-3, f"{what}: rel-L2 {r}"
+
+
+def _rand_bf16(shape, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale).to(torch.bfloat16)
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, pad, relu, residual
+    (2, 8, 8, 64, 64, 1, 1, 0, True, False),
+    (3, 5, 5, 64, 256, 1, 1, 0, True, True),       # M = 75: ragged pixel tail, residual epilogue
+    (2, 8, 8, 256, 512, 1, 2, 0, False, False),    # strided 1x1 (downsample), no ReLU
+    (3, 7, 7, 64, 64, 3, 1, 1, True, False),       # 3x3, padding edges, M = 147
+    (2, 9, 9, 128, 128, 3, 2, 1, True, False),     # 3x3 stride 2, odd size
+    (1, 14, 14, 256, 256, 3, 1, 1, True, True),
+    (2, 7, 7, 512, 512, 3, 1, 1, True, False),     # layer4 conv2 shape, K = 4608
+    (2, 7, 7, 2048, 512, 1, 1, 0, True, False),    # K = 2048
+    (1, 56, 56, 64, 256, 1, 1, 0, True, True),     # layer1 conv3 at full spatial size
+    (1, 1, 1, 64, 64, 3, 1, 1, True, False),       # single pixel: every tap but the centre is padding
+]
+
+
+def _tiles_for(cout):
+    from implementation_phd_lab_vision_amd import ops
+    t = [ops.TILE_AUTO, ops.TILE_64x128, ops.TILE_64x256]
+    if cout % 128 == 0:
+        t += [ops.TILE_128x128, ops.TILE_128x64]
+    if cout % 256 == 0:
+        t += [ops.TILE_256x128]
+    return t
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "n%d_%dx%d_c%d-%d_k%ds%dp%d_r%d_res%d" % tuple(int(v) for v in c))
+def test_conv2d_matches_oracle(lib_built, case):
+    from implementation_phd_lab_vision_amd import ops
+    from oracle.resnet50_oracle import conv_bias_act_emulated
+    n, h, w, cin, cout, k, stride, pad, relu, has_res = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = _rand_bf16((n, cin, h, w), g)
+    wt = _rand_bf16((cout, cin, k, k), g, scale=(2.0 / (cin * k * k)) ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    ho = (h + 2 * pad - k) // stride + 1
+    wo = (w + 2 * pad - k) // stride + 1
+    res = _rand_bf16((n, cout, ho, wo), g) if has_res else None
+    ref = conv_bias_act_emulated(x.float(), wt.float(), bias, stride, pad, relu,
+                                 residual_bf=res.float() if has_res else None)
+    d = _dev()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(d)
+    wd = wt.permute(0, 2, 3, 1).contiguous().to(d)
+    bd = bias.to(d)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(d) if has_res else None
+    for tile in _tiles_for(cout):
+        for stage in (0, ops.REG_STAGE):
+            if tile == ops.TILE_AUTO and stage:
+                continue
+            y = ops.conv2d_bf16(xd, wd, bd, stride=stride, pad=pad, relu=relu, residual=rd, tile=tile | stage)
+            torch.cuda.synchronize()
+            _check_bf16(y, ref, f"conv tile={tile} stage={stage}")
+
+
+def test_conv2d_identity_asymmetric(lib_built):
+    """A = I check with an asymmetric B (cdna guide §3): 1x1 conv with identity weights must return
+    the input exactly; a transposed operand or C/D map cannot pass."""
+    from implementation_phd_lab_vision_amd import ops
+    d = _dev()
+    n, h, w, c = 2, 6, 5, 128
+    x = torch.arange(n * h * w * c, dtype=torch.float32).remainder(251.0).sub(125.0).view(n, h, w, c).to(torch.bfloat16)
+    wt = torch.eye(c).view(c, 1, 1, c).to(torch.bfloat16)
+    for tile in (ops.TILE_64x128, ops.TILE_128x128, ops.TILE_128x64, ops.TILE_64x256):
+        for stage in (0, ops.REG_STAGE):
+            y = ops.conv2d_bf16(x.to(d), wt.to(d), torch.zeros(c, device=d), relu=False, tile=tile | stage)
+            assert torch.equal(y.cpu(), x), f"identity conv mismatch, tile {tile} stage {stage}"
+
+
+def test_conv2d_rejects_bad_shapes(lib_built):
+    from implementation_phd_lab_vision_amd import ops, _lib
+    d = _dev()
+    x = torch.zeros((1, 4, 4, 32), dtype=torch.bfloat16, device=d)       # cin % 64 != 0
+    wt = torch.zeros((64, 1, 1, 32), dtype=torch.bfloat16, device=d)
+    with pytest.raises(_lib.R50Error):
+        ops.conv2d_bf16(x, wt, torch.zeros(64, device=d))
+
+
+@pytest.mark.parametrize("n", [1, 3])
+def test_stem_matches_oracle(lib_built, n):
+    from implementation_phd_lab_vision_amd import ops
+    from implementation_phd_lab_vision_amd.weights import synthetic_frames, synthetic_state_dict
+    from oracle.resnet50_oracle import bf16_round, conv_bias_act_emulated, folded
+    sd = synthetic_state_dict(0)
+    wf, bf = folded(sd, "conv1", "bn1")
+    x = synthetic_frames(n, seed=7)
+    ref = conv_bias_act_emulated(bf16_round(x), wf, bf, 2, 3, True)
+    d = _dev()
+    y = ops.stem_bf16(x.to(d), wf, bf.to(d))
+    torch.cuda.synchronize()
+    _check_bf16(y, ref, "stem")
+
+
+@pytest.mark.parametrize("shape", [(2, 112, 112, 64), (1, 7, 9, 8), (3, 5, 5, 72)])
+def test_maxpool_bit_exact(lib_built, shape):
+    from implementation_phd_lab_vision_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    x = _rand_bf16(shape, g)                       # negative values too: padding must act as -inf
+    ref = F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+    y = ops.maxpool_bf16(x.to(_dev()))
+    assert torch.equal(y.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("shape", [(4, 7, 7, 2048), (1, 3, 3, 8)])
+def test_avgpool_matches_oracle(lib_built, shape):
+    from implementation_phd_lab_vision_amd import ops
+    g = torch.Generator().manual_seed(13)
+    x = _rand_bf16(shape, g)
+    n, h, w, c = shape
+    ref = x.double().view(n, h * w, c).mean(dim=1)
+    y = ops.avgpool_bf16(x.to(_dev())).cpu().double()
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6), float((y - ref).abs().max())
