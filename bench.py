@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: ResNet-50 feature extraction, frames/s on synthetic 224x224x3 frames.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch: BATCH (256) fp32 NCHW frames per GPU, already
+resident in HBM, -> (BATCH, 2048) fp32 features (= backbone(x).flatten(1),
+/root/reference/src/preprocess_resnet_features.py:296); for N > 1 each rank owns its own frames
+(weak scaling) and the features return to rank 0 with one RCCL gather per step.
+Prints ONE JSON line on rank 0 (contract in the task statement), including:
+  roofline     — the implicit-GEMM conv kernel class (52 of the 56 launches per step): algorithmic
+                 FLOPs / HIP-event time of those launches, measured live on the launch stream.
+  cpu_baseline — the CPU restatement of the reference's fp32 path (oracle/) timed on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+BATCH = 256
+GFLOP_PER_FRAME = 8.174272512          # 2 x 4,087,136,256 MAC, 53 convs
+MFMA_BF16_PEAK_TFLOPS = 2500.0         # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: min(affinity, cgroup quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:                                            # cgroup v2 quota, e.g. "1600000 100000"
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    env = os.environ.get("R50_CPU_THREADS")
+    if env:
+        n = int(env)
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(sample_frames: int = 64, reps: int = 5) -> dict:
+    """Reference's CPU numerics (fp32, autocast off, :239-241) via the oracle restatement, on the host cores."""
+    from implementation_phd_lab_vision_amd.weights import synthetic_frames, synthetic_state_dict
+    from oracle import resnet50_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = synthetic_state_dict(0)
+    x = synthetic_frames(sample_frames, seed=1234)
+    O.forward_reference(sd, x)                      # warm-up
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        O.forward_reference(sd, x)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": sample_frames / med, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_frames} frames x {reps} timed forwards (median), fp32 torch.nn.functional restatement "
+                      f"of torchvision resnet50[:-1], torch {torch.__version__}"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="frames per GPU per step (headline config: 256)")
+    ap.add_argument("--micro-batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+
+    from implementation_phd_lab_vision_amd import _lib
+    from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
+    from implementation_phd_lab_vision_amd.weights import synthetic_frames, synthetic_state_dict
+
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    if rank == 0:
+        _lib.build_library()
+    if dist is not None:
+        dist.barrier()
+
+    sd = synthetic_state_dict(0)
+    bb = ResNet50Backbone(state_dict=sd, max_batch=args.batch, micro_batch=args.micro_batch).to(dev).eval()
+    x = synthetic_frames(args.batch, seed=1234 + rank).to(dev)          # random data, resident in HBM
+    feats = torch.empty((args.batch, 2048), dtype=torch.float32, device=dev)
+    gathered = [torch.empty_like(feats) for _ in range(world)] if (dist is not None and rank == 0) else None
+
+    def step():
+        bb.features(x, out=feats)
+        if dist is not None:
+            dist.gather(feats, gathered, dst=0)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel-class HIP-event timing on the launch stream (rank 0, same steps again) ----
+    roofline = None
+    kernels = None
+    if rank == 0:
+        bb.set_option("profile", 1)
+        bb.profile_reset()
+        for _ in range(args.steps):
+            bb.features(x, out=feats)
+        torch.cuda.synchronize(dev)
+        prof = bb.profile_collect()
+        bb.set_option("profile", 0)
+        ig = prof["igemm"]
+        achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "igemm_bf16_kernel (52 conv launches/step)", "achieved": achieved,
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+                    "traffic": None,
+                    "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
+                    "flops_per_launch": ig["flops"] / max(1, ig["launches"]),
+                    "layerwise_GBps": ig["bytes"] / (ig["ms"] * 1e-3) / 1e9 if ig["ms"] > 0 else 0.0}
+        tot_ms = sum(v["ms"] for v in prof.values())
+        kernels = {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["ms"] / args.steps,
+                       "share": v["ms"] / tot_ms if tot_ms else 0.0} for k, v in prof.items()}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+    if rank == 0:
+        frames = world * args.batch * args.steps
+        value = frames / elapsed
+        out = {
+            "metric": "H36M frames/sec ResNet-50 feature extraction",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"ResNet-50[:-1] bf16 forward, batch {args.batch} x 224x224x3 fp32 NCHW frames per GPU "
+                                   f"(BASELINE configs[1]), seeded synthetic weights, (N,2048) fp32 features"
+                                   + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "batch_per_gpu": args.batch, "micro_batch": args.micro_batch,
+                       "parallelism": f"frames sharded over {world} rank(s)"},
+            "tflops": value * GFLOP_PER_FRAME / 1e3,
+            "frac_of_mfma_peak_whole_step": value * GFLOP_PER_FRAME / 1e3 / MFMA_BF16_PEAK_TFLOPS / world,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

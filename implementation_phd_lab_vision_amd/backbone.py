@@ -131,6 +131,24 @@ class ResNet50Backbone:
         d = [int(v) for v in dims]
         return buf[: d[0] * d[1] * d[2] * d[3]].view(*d)
 
+    def packed_params(self, conv_key: str):
+        """Debug hook: (folded bf16 weights in (cout,k,k,cin) order, folded fp32 bias) as the device holds them."""
+        from .weights import conv_specs
+        spec = {c[0]: c for c in conv_specs()}[conv_key]
+        _ck, _bk, cin, cout, k, _s, _p = spec
+        lib = _lib.load_library()
+        n = C.c_int64()
+        wbytes = 7 * 64 * 64 if conv_key == "conv1" else cout * k * k * cin * 2
+        w = torch.empty(wbytes // 2, dtype=torch.bfloat16)
+        _lib.check(lib.r50_get_packed(self._handle, conv_key.encode(), 0, w.data_ptr(), wbytes, C.byref(n)),
+                   self._handle, "r50_get_packed")
+        b = torch.empty(cout, dtype=torch.float32)
+        _lib.check(lib.r50_get_packed(self._handle, conv_key.encode(), 1, b.data_ptr(), cout * 4, C.byref(n)),
+                   self._handle, "r50_get_packed")
+        if conv_key != "conv1":
+            w = w.view(cout, k, k, cin)
+        return w, b
+
     # ---- options / profiling ----------------------------------------------------------------
     def set_option(self, key: str, value: int) -> None:
         _lib.check(_lib.load_library().r50_set_option(self._handle, key.encode(), int(value)), self._handle, "r50_set_option")

@@ -568,6 +568,27 @@ int r50_profile_entry(r50_handle* h, int i, const char** name, int64_t* launches
     return R50_OK;
 }
 
+int r50_get_packed(r50_handle* h, const char* conv_key, int what, void* dst_host, int64_t capacity_bytes,
+                   int64_t* bytes_out) {
+    if (!h || !conv_key || !dst_host || !bytes_out) return fail(h, R50_ERR_INVALID, "r50_get_packed: null argument");
+    if (!h->loaded) return fail(h, R50_ERR_STATE, "r50_get_packed: weights not loaded");
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (size_t i = 0; i < h->convs.size(); ++i) {
+        const ConvLayer& L = h->convs[i];
+        if (L.conv_key != conv_key) continue;
+        const void* src;
+        int64_t bytes;
+        if (what == 1) { src = L.bias; bytes = (int64_t)L.cout * 4; }
+        else if (i == 0) { src = h->stem_w; bytes = STEM_W_BYTES; }
+        else { src = L.w; bytes = (int64_t)L.cout * L.ks * L.ks * L.cin * 2; }
+        *bytes_out = bytes;
+        if (bytes > capacity_bytes) return fail(h, R50_ERR_INVALID, "r50_get_packed: buffer too small");
+        HIP_TRY(h, hipMemcpy(dst_host, src, bytes, hipMemcpyDeviceToHost));
+        return R50_OK;
+    }
+    return fail(h, R50_ERR_INVALID, std::string("r50_get_packed: unknown conv ") + conv_key);
+}
+
 // ---- op-level entry points -------------------------------------------------------------------
 int r50_op_conv2d(const void* x, int n, int h, int w, int cin, const void* wt, const float* bias, const void* res,
                   void* y, int cout, int ksize, int stride, int pad, int relu, int tile, void* stream) {

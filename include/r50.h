@@ -89,6 +89,12 @@ int r50_profile_count(r50_handle* h);
 int r50_profile_entry(r50_handle* h, int i, const char** name, int64_t* launches, double* total_ms,
                       double* flops, double* bytes);
 
+/* Debug hook: copy the folded+packed parameters of one conv back to the host (BN-fold parity
+ * tests).  conv_key e.g. "layer2.0.downsample.0"; what: 0 = bf16 weights in (cout,k,k,cin) order
+ * (stem: the kernel's [kh][row][8][4] image), 1 = fp32 folded bias. */
+int r50_get_packed(r50_handle* h, const char* conv_key, int what, void* dst_host, int64_t capacity_bytes,
+                   int64_t* bytes_out);
+
 const char* r50_last_error(r50_handle* h);   /* h may be NULL: last error of r50_create / r50_op_* */
 void r50_destroy(r50_handle* h);             /* replaces: del backbone */
 const char* r50_version(void);

@@ -3,8 +3,10 @@ CPU oracle (oracle/resnet50_oracle.py) on the same seeded bf16 inputs.
 
 Tolerance (stated once, used everywhere below): the device accumulates bf16 x bf16 products in fp32
 (MFMA) where the oracle accumulates in fp64, then both round to bf16.  So outputs must agree to
-within ONE bf16 ulp element-wise (|d| <= 2^-7 * max(|ref|, tiny) ), at most 1 % of elements may
-differ at all, and the tensor rel-L2 must be < 1e-3.
+within ONE bf16 ulp element-wise, plus an absolute term for results that are the cancellation of
+O(1) terms (fp32 accumulation noise ~ 2^-16 of the tensor's scale):
+|d| <= 2^-7 * |ref| + 2^-16 * max(1, max|ref|); at most 1 % of elements may differ at all, and the
+tensor rel-L2 must be < 1e-3.
 """
 import pytest
 import torch
@@ -23,9 +25,9 @@ def _check_bf16(dev_nhwc: torch.Tensor, ref_nchw: torch.Tensor, what: str):
     assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
     assert torch.isfinite(got).all(), f"{what}: non-finite output"
     diff = (got - ref).abs()
-    ulp = ref.abs().clamp_min(2.0 ** -20) * 2.0 ** -7
+    ulp = ref.abs() * 2.0 ** -7 + 2.0 ** -16 * max(1.0, float(ref.abs().max()))
     bad = diff > ulp
-    assert not bad.any(), f"{what}: {int(bad.sum())} elements beyond 1 bf16 ulp, max diff {float(diff.max())}"
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements beyond tolerance, max diff {float(diff.max())}"
     frac = float((diff > 0).float().mean())
     assert frac < 0.01, f"{what}: {frac:.4f} of elements differ"
     r = rel_l2(got, ref)

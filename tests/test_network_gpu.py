@@ -2,10 +2,13 @@
 (`backbone.to(device).eval(); backbone(x)`, src/preprocess_resnet_features.py:209,296).
 
 Tolerances:
-* vs the bf16-emulating oracle (same rounding points, fp64 accumulation): named activations rel-L2
-  < 2e-3, final per-frame feature rel-L2 < 3e-3.  (Two oracles that differ only in accumulating in
-  fp32 vs fp64 already sit 9e-4 apart end to end on these weights: bf16 re-rounding amplifies
-  accumulation-order noise, so this is the floor for a bf16 pipeline, not kernel error.)
+* every conv of the network on SHARED inputs (the device's own input activation fed to the oracle's
+  fused conv): within one bf16 ulp + 2^-16 of scale per element (same bar as test_kernels_gpu.py).
+* free-running, vs the bf16-emulating oracle (same rounding points, fp64 accumulation): two CPU
+  emulations that differ ONLY in accumulating in fp32 instead of fp64 drift apart layer by layer
+  (bf16 re-rounding amplifies accumulation-order noise: 1e-5 at the stem, 6e-3 element-wise at
+  layer4, 1e-3 on the pooled features).  The device must stay within 3x that measured drift per
+  named activation, and within 3e-3 per-frame rel-L2 on the final features.
 * vs the fp32 reference restatement (the reference's CPU numerics): per-frame rel-L2 < 1e-2 — the
   cost of bf16 itself (the reference's own GPU path runs bf16 autocast, :290-294).
 """
@@ -27,26 +30,70 @@ def setup(lib_built):
     x = synthetic_frames(4, seed=1234)
     taps = {}
     feats_emu = O.forward_bf16_emulated(sd, x, taps=taps)
+    taps32 = {}
+    O.forward_bf16_emulated(sd, x, taps=taps32, acc_dtype=torch.float32)
+    drift = {k: O.rel_l2(taps32[k], taps[k]) for k in taps}
     feats_ref = O.forward_reference(sd, x).flatten(1)
     bb = ResNet50Backbone(state_dict=sd, max_batch=8).to("cuda:0").eval()
-    return bb, x, taps, feats_emu, feats_ref
+    return bb, x, (taps, drift, sd), feats_emu, feats_ref
 
 
 def test_named_activations_match_emulated_oracle(setup):
     from oracle.resnet50_oracle import rel_l2
-    bb, x, taps, _, _ = setup
+    bb, x, (taps, drift, _sd), _, _ = setup
     xd = x.to("cuda:0")
     for name in TAPS:
         got = bb.layer(xd, name).float().cpu().permute(0, 3, 1, 2)
         ref = taps[name].float()
         assert got.shape == ref.shape, name
         r = rel_l2(got, ref)
-        assert r < 2e-3, f"{name}: rel-L2 {r}"
+        assert r < max(1e-4, 3.0 * drift[name]), f"{name}: rel-L2 {r} (emulation drift {drift[name]})"
+
+
+def test_every_conv_on_shared_inputs(setup):
+    """All 52 bottleneck convs, each checked in isolation: the oracle's fused conv is fed the DEVICE's
+    input activation (and residual), so no drift accumulates and the 1-ulp bar applies."""
+    from oracle.resnet50_oracle import conv_bias_act_emulated, folded
+    from tests.test_kernels_gpu import _check_bf16
+    bb, x, (_taps, _drift, sd), _, _ = setup
+    xd = x[:2].to("cuda:0")
+
+    def dev(name):
+        return bb.layer(xd, name)                       # bf16 NHWC on the GPU
+
+    def nchw(t):
+        return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+    prev = "pool"
+    n_checked = 0
+    for si, (blocks, stride) in enumerate(((3, 1), (4, 2), (6, 2), (3, 2)), start=1):
+        for b in range(blocks):
+            p = f"layer{si}.{b}"
+            s = stride if b == 0 else 1
+            x_in = nchw(dev(prev))
+            t1, t2, out = dev(p + ".t1"), dev(p + ".t2"), dev(p)
+            w, bias = folded(sd, p + ".conv1", p + ".bn1")
+            _check_bf16(t1, conv_bias_act_emulated(x_in, w, bias, 1, 0, True), p + ".conv1")
+            w, bias = folded(sd, p + ".conv2", p + ".bn2")
+            _check_bf16(t2, conv_bias_act_emulated(nchw(t1), w, bias, s, 1, True), p + ".conv2")
+            if b == 0:
+                ds = dev(p + ".ds")
+                w, bias = folded(sd, p + ".downsample.0", p + ".downsample.1")
+                _check_bf16(ds, conv_bias_act_emulated(x_in, w, bias, s, 0, False), p + ".downsample")
+                idn = nchw(ds)
+                n_checked += 1
+            else:
+                idn = x_in
+            w, bias = folded(sd, p + ".conv3", p + ".bn3")
+            _check_bf16(out, conv_bias_act_emulated(nchw(t2), w, bias, 1, 0, True, residual_bf=idn), p + ".conv3")
+            n_checked += 3
+            prev = p
+    assert n_checked == 52
 
 
 def test_features_match_oracles(setup):
     from oracle.resnet50_oracle import per_row_rel_l2
-    bb, x, _, feats_emu, feats_ref = setup
+    bb, x, _t, feats_emu, feats_ref = setup
     out = bb(x.to("cuda:0"))
     assert tuple(out.shape) == (4, 2048, 1, 1) and out.dtype == torch.float32 and out.is_cuda
     f = out.flatten(1).cpu()
