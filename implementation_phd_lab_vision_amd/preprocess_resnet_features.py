@@ -1,0 +1,260 @@
+"""CLI: H36M clips -> per-frame ResNet-50 features -> shuffled ``shard_XXXXX.pt`` + ``index.pt``.
+
+MI355X-native replacement of /root/reference/src/preprocess_resnet_features.py ``main()`` (:134-428):
+the same 14 flags (:136-155) and the same output contract (shards.py), so the reference's
+``src/dataset_features.py`` and ``src/train.py`` consume the result unchanged.  What changes is the
+engine: the backbone is ``ResNet50Backbone`` (hand-written HIP kernels behind include/r50.h) instead of
+torchvision + autocast + torch.compile, and multi-GPU is one process per GPU (``torchrun``) with an
+RCCL gather of the feature blocks instead of ``nn.DataParallel`` (distributed.py).
+
+    python -m implementation_phd_lab_vision_amd.preprocess_resnet_features --root R --out O [...]
+    torchrun --standalone --local-addr 127.0.0.1 --nproc-per-node 8 -m \
+        implementation_phd_lab_vision_amd.preprocess_resnet_features --root R --out O [...]
+
+The clip dataset is the reference's own ``Human36MPreprocessedClips`` (src/dataset.py), imported from
+``$H36M_REFERENCE_SRC`` or ``sys.path`` — the frame producer is upstream of this path.  Extra,
+optional flags (defaults keep the reference behaviour): ``--weights`` (local torchvision checkpoint;
+otherwise seeded synthetic weights — nothing is downloaded), ``--synthetic-clips N`` (run without
+H36M data), ``--micro-batch``, ``--max-batch``.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+from pathlib import Path
+from typing import Callable, List, Optional
+
+import torch
+from torch.utils.data import DataLoader, Subset
+
+from . import distributed as D
+from .shards import AUG_NAMES, AsyncFileWriter, ShardPacker
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser("Precompute per-clip ResNet50 features for H36M (MI355X-native)")
+    # ---- the reference's 14 flags, verbatim (:137-153) ----
+    p.add_argument("--root", type=str, required=True, help="H36M preprocessed root")
+    p.add_argument("--out", type=str, required=True, help="Output directory for cached features")
+    p.add_argument("--seq-len", type=int, default=40)
+    p.add_argument("--frame-skip", type=int, default=2)
+    p.add_argument("--stride", type=int, default=5)
+    p.add_argument("--batch-size", type=int, default=32)
+    p.add_argument("--num-workers", type=int, default=8)
+    p.add_argument("--subjects", type=int, nargs="+", default=[1, 5, 6, 7, 8, 9, 11])
+    p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--save-fp16", action="store_true", help="Store feats as float16")
+    p.add_argument("--augment", action="store_true", help="Write the 4 augmentation variants per clip")
+    p.add_argument("--shard-size", type=int, default=512, help="Number of clips per shard file")
+    p.add_argument("--shuffle-pool", type=int, default=8192, help="Clips accumulated before a shuffle + flush")
+    p.add_argument("--shuffle-seed", type=int, default=123, help="Seed for clip-level shuffling")
+    # ---- additions (optional) ----
+    p.add_argument("--weights", type=str, default=None, help="Local torchvision resnet50-*.pth (default: seeded synthetic)")
+    p.add_argument("--weights-seed", type=int, default=0)
+    p.add_argument("--synthetic-clips", type=int, default=0, help="Use N synthetic clips instead of reading --root")
+    p.add_argument("--micro-batch", type=int, default=0, help="Frames per pass through the layer stack (0 = auto)")
+    p.add_argument("--max-batch", type=int, default=256, help="Frames per backbone call chunk (workspace size)")
+    return p
+
+
+def collate_variants(batch):
+    """augment=True items are lists of variants: collate each variant across the batch -> list of
+    (videos, joints3d, joints2d, K), one per variant (reference: augment_collate_fn, :59-69)."""
+    stacked = []
+    for v in range(len(batch[0])):
+        cols = list(zip(*[sample[v][:4] for sample in batch]))
+        stacked.append(tuple(torch.stack(col) for col in cols))
+    return stacked
+
+
+augment_collate_fn = collate_variants       # the reference's name for it
+
+
+def _open_dataset(args):
+    if args.synthetic_clips > 0:
+        from .synthetic import SyntheticClips
+        return SyntheticClips(args.synthetic_clips, seq_len=args.seq_len, subjects=tuple(args.subjects),
+                              augment=args.augment, stride=args.stride)
+    src = os.environ.get("H36M_REFERENCE_SRC")
+    if src and src not in sys.path:
+        sys.path.insert(0, src)
+    try:
+        from dataset import Human36MPreprocessedClips      # the reference's src/dataset.py
+    except Exception as exc:
+        raise SystemExit(
+            "cannot import the reference's clip dataset (src/dataset.py: Human36MPreprocessedClips, needs "
+            f"torchvision.io): {exc!r}\nPoint H36M_REFERENCE_SRC at the reference's src/ directory, or use "
+            "--synthetic-clips N to run the feature path without H36M data.")
+    return Human36MPreprocessedClips(root=args.root, subjects=args.subjects, seq_len=args.seq_len,
+                                     frame_skip=args.frame_skip, stride=args.stride, augment=args.augment,
+                                     max_clips=None)
+
+
+def _resolve_device(name: str, ctx: D.RankContext) -> torch.device:
+    if not name.startswith("cuda"):
+        raise SystemExit(f"--device {name}: this build runs the backbone on an MI355X only (PyTorch-ROCm exposes it "
+                         "as 'cuda'); there is no CPU path")
+    if not torch.cuda.is_available():
+        raise SystemExit("no GPU visible: the HIP feature path cannot run (the reference would fall back to CPU "
+                         "torchvision here, :157-161; this build fails loudly instead)")
+    if ctx.distributed:
+        return torch.device("cuda", ctx.local_rank)
+    dev = torch.device(name)
+    return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+def extract_features(backbone: Callable[[torch.Tensor], torch.Tensor], variants_batch, device: torch.device) -> torch.Tensor:
+    """The hot call site (:287-297): every variant's (B,T,3,224,224) clip batch -> (B,T,2048) fp32.
+    Returns (B, V, T, 2048) on ``device``."""
+    per_variant = []
+    for v_video, *_ in variants_batch:
+        v_video = v_video.to(device, non_blocking=True)
+        b, t, c, h, w = v_video.shape
+        x = v_video.view(b * t, c, h, w).contiguous()
+        per_variant.append(backbone(x).flatten(1).view(b, t, -1).to(torch.float32))
+    return torch.stack(per_variant, dim=1)
+
+
+def _host_payload(variants_batch, box_batch):
+    """The cheap per-clip annotations that ride to rank 0 beside the features."""
+    return {"vars": [(j3d.cpu(), j2d.cpu(), k.cpu()) for _v, j3d, j2d, k in variants_batch],
+            "box": None if box_batch is None else box_batch.cpu()}
+
+
+def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.RankContext] = None,
+                   log: Callable[[str], None] = print) -> Optional[Path]:
+    """Whole job for one rank.  ``backbone(x)``: (N,3,224,224) fp32 on ``device`` -> (N,2048,1,1).
+    Rank 0 packs and returns the index path; other ranks return None."""
+    ctx = ctx or D.RankContext()
+    n_vars = len(AUG_NAMES) if args.augment else 1
+    n_clips = len(ds)
+    bs = args.batch_size
+    feat_dtype = torch.float16 if args.save_fp16 else torch.float32
+
+    mine = D.rank_clip_indices(n_clips, bs, ctx.rank, ctx.world)
+    loader = None
+    if mine:
+        kw = dict(batch_size=bs, shuffle=False, num_workers=args.num_workers, pin_memory=device.type == "cuda",
+                  drop_last=False, collate_fn=collate_variants if args.augment else None)
+        if args.num_workers > 0:
+            kw["prefetch_factor"] = 2
+        loader = DataLoader(Subset(ds, mine) if ctx.distributed else ds, **kw)
+    it = iter(loader) if loader is not None else None
+
+    packer = None
+    if ctx.is_root:
+        packer = ShardPacker(args.out, n_vars, args.shard_size, args.shuffle_pool, args.shuffle_seed, AsyncFileWriter())
+        log(f"Processing {n_clips} clips × {n_vars} variant(s) = {n_clips * n_vars} entries …")
+        log(f"Writing shards of {args.shard_size} clips each → {packer.out_root}")
+        log("-" * 60)
+
+    t_all = t_last = time.time()
+    done = 0
+    my_batches = (D.n_batches(n_clips, bs) - ctx.rank + ctx.world - 1) // ctx.world if n_clips else 0
+    for q in range(D.n_rounds(n_clips, bs, ctx.world)):
+        feats = payload = None
+        if q < my_batches:
+            batch = next(it)
+            if args.augment:
+                variants_batch, box_batch = batch, None
+            else:
+                video, j3d, j2d, k, box = batch
+                variants_batch, box_batch = [(video, j3d, j2d, k)], box
+            feats = extract_features(backbone, variants_batch, device)
+            payload = _host_payload(variants_batch, box_batch)
+            t = variants_batch[0][0].shape[1]
+        else:
+            t = args.seq_len
+        blocks = D.gather_features(ctx, feats, (bs, n_vars, t, 2048), device)
+        payloads = D.gather_objects(ctx, payload)
+        if not ctx.is_root:
+            continue
+        for r in range(ctx.world):                     # rank order == global clip order
+            g = q * ctx.world + r
+            clips = D.batch_clip_range(g, n_clips, bs)
+            if len(clips) == 0:
+                continue
+            blk, pay = blocks[r].to(feat_dtype), payloads[r]
+            if blk.shape[0] != len(clips):
+                raise RuntimeError(f"rank {r} sent {blk.shape[0]} clips for batch {g}, expected {len(clips)}")
+            for b, ci in enumerate(clips):
+                rec = ds.index[ci]
+                group = []
+                for v in range(n_vars):
+                    j3d, j2d, k = pay["vars"][v]
+                    group.append({
+                        "feat": blk[b, v],
+                        "joints3d": j3d[b],
+                        "joints2d": j2d[b],
+                        "K": k[b] if k.ndim >= 3 else k,
+                        "meta": {"subject": rec.subject, "action": rec.action, "cam": rec.cam, "start": rec.start,
+                                 "end": rec.end, "aug": AUG_NAMES[v] if args.augment else "orig",
+                                 "box": pay["box"][b] if pay["box"] is not None else None},
+                    })
+                packer.add_group(group)
+                done += 1
+            if done % 200 == 0 or done == n_clips:
+                dt = time.time() - t_last
+                rate = 200 / dt if dt > 0 else 0.0
+                t_last = time.time()
+                eta = (n_clips - done) / rate if rate > 0 else 0.0
+                log(f"[{100 * done / n_clips:5.1f}%] {done:6d}/{n_clips} clips | {rate:6.1f} clips/s | ETA {eta:6.1f}s | "
+                    f"shard {packer.shard_id} (pool: {len(packer.pool)} clips, carry: {len(packer.carry)} clips)")
+
+    if not ctx.is_root:
+        return None
+    packer.finish()
+    log("\nWaiting for all shards to be written to disk...")
+    index_path = packer.write_index(seq_len=args.seq_len, frame_skip=args.frame_skip, save_fp16=args.save_fp16,
+                                    augment=args.augment, n_clips=n_clips)
+    log("✓ All shards written and index saved.")
+    total = time.time() - t_all
+    log("-" * 60)
+    log(f"✓ Done!  {n_clips} clips × {n_vars} variant(s) packed into {packer.shard_id} shard(s)")
+    log(f"✓ Total time        : {total:.1f}s")
+    log(f"✓ Throughput        : {n_clips / total:.1f} clips/s  ({n_clips * n_vars / total:.1f} variant entries/s)")
+    log(f"✓ Avg time per clip : {1000 * total / max(1, n_clips):.1f} ms")
+    return index_path
+
+
+@torch.no_grad()
+def main(argv: Optional[List[str]] = None) -> None:
+    args = build_parser().parse_args(argv)
+    ctx = D.init_from_env(use_gpu=True)
+    device = _resolve_device(args.device, ctx)
+    torch.cuda.set_device(device)
+    log = print if ctx.is_root else (lambda *_a, **_k: None)
+
+    log(f"Device     : {device}  ({torch.cuda.get_device_name(device)}), ranks: {ctx.world}")
+    n_vars = len(AUG_NAMES) if args.augment else 1
+    log(f"Augment    : {args.augment}  ({'4 variants/clip → ' + ', '.join(AUG_NAMES) if args.augment else 'none'})")
+    log(f"Shard size : {args.shard_size} clips  ({args.shard_size * n_vars} variant entries/shard)")
+
+    from . import _lib
+    from .backbone import ResNet50Backbone
+    if ctx.is_root:
+        _lib.build_library()
+    if ctx.distributed:
+        torch.distributed.barrier()
+    ds = _open_dataset(args)
+    backbone = ResNet50Backbone(weights_path=args.weights, seed=args.weights_seed, max_batch=args.max_batch,
+                                micro_batch=args.micro_batch).to(device).eval()
+
+    log("Warming up the HIP kernels...")                               # reference warm-up: :235-245
+    warm = torch.zeros((min(args.max_batch, args.batch_size * args.seq_len), 3, 224, 224), device=device)
+    backbone(warm)
+    torch.cuda.synchronize(device)
+    del warm
+    log("✓ Warmup complete\n")
+
+    try:
+        run_extraction(ds, args, backbone, device, ctx, log)
+    finally:
+        backbone.close()
+        D.shutdown(ctx)
+
+
+if __name__ == "__main__":
+    main()
