@@ -13,7 +13,7 @@ from pathlib import Path
 from typing import Optional
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libr50hip.so"
+LIB_PATH = Path(os.environ.get("R50_LIB", str(PKG_DIR / "libr50hip.so")))   # R50_LIB: diagnostic builds only
 CSRC = PKG_DIR / "csrc"
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
@@ -30,6 +30,8 @@ class TensorDesc(C.Structure):
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     """Compile csrc/r50_abi.hip for gfx950 into libr50hip.so (in-tree)."""
     srcs = [CSRC / "r50_abi.hip", CSRC / "kernels.h", PKG_DIR.parent / "include" / "r50.h"]
+    if "R50_LIB" in os.environ:
+        return LIB_PATH
     if LIB_PATH.exists() and not force:
         if all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs if s.exists()):
             return LIB_PATH

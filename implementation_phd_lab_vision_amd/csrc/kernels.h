@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -57,6 +58,9 @@ struct ConvArgs {
     int Ktot;             // ks*ks*Cin
     int n_ctiles;         // Cout / BC
     int n_blocks;
+    int x_back;           // bytes the X descriptor base sits before x: (pad*W + pad)*Cin*2
+    unsigned x_records;   // X descriptor size: activation bytes + x_back (< 2^31)
+    unsigned w_bytes;     // W descriptor size
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -67,15 +71,47 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + (bid >> 3);
 }
 
-template <int BC, int BP, int WC, int WP, bool GLDS>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(const ConvArgs a) {
-    static_assert(WC * WP == 4, "4 waves");
+// MODE: 0 = LDS-DMA staging, 2 LDS stages, one barrier per K-step (vmcnt(0) before it);
+//       1 = register staging (buffer_load_dwordx4 -> ds_write_b128), 2 LDS stages;
+//       2 = LDS-DMA staging, 3 LDS stages, raw s_barrier + COUNTED vmcnt: two K-steps of loads stay in
+//           flight across the barrier (one workgroup of 8 waves per CU).
+//
+// Addressing (the K loop carries almost no vector ALU work): both operands are fetched with
+// buffer_load_dwordx4 [... lds]: address = SRD base + per-lane voffset (fixed for the whole kernel)
+// + scalar soffset (the K-step's uniform displacement).
+//   W: voffset = (cout_row * Ktot + chunk*8) * 2,  soffset = step * 128.
+//   X: voffset = byte offset of the lane's pixel at the REFERENCE tap (pad,pad) -- always inside
+//      the image -- and soffset = ((dh*W + dw)*Cin + cc*64) * 2 against an SRD base moved back by
+//      (pad*W + pad)*Cin*2 bytes, so every component is non-negative.  A lane whose tap falls in the
+//      padding (or whose row is past M) uses voffset = 2^31 >= num_records: the buffer range check
+//      returns zeros for it (requires activation bytes < 2^31, checked on the host).
+enum { IGEMM_GLDS2 = 0, IGEMM_REG2 = 1, IGEMM_GLDS3 = 2 };
+
+// Diagnostic builds only (scripts/ablate.sh): R50_ABLATE = 1 no global loads inside the K loop,
+// 2 = no MFMAs (fragment reads kept alive), 3 = no fragment reads and no MFMAs (fill rate only).
+#ifndef R50_ABLATE
+#define R50_ABLATE 0
+#endif
+
+constexpr unsigned kOobOffset = 0x80000000u;
+
+template <int BC, int BP, int WC, int WP, int MODE>
+__global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // body only in the device pass: the host pass needs just the launch stub
+                                      // (the LDS-DMA buffer builtin has no host-side lowering)
+    constexpr int NT = WC * WP * 64;      // threads per workgroup
+    constexpr bool GLDS = (MODE != IGEMM_REG2);
+    constexpr int NSTAGE = (MODE == IGEMM_GLDS3) ? 3 : 2;
     constexpr int MR = BC / WC / 16;      // cout blocks per wave
     constexpr int NR = BP / WP / 16;      // pixel blocks per wave
     static_assert(MR >= 2 && (MR % 2) == 0, "wave needs >= 32 couts");
-    constexpr int WROWS = BC / 32;        // staging rows per thread
-    constexpr int XROWS = BP / 32;
+    constexpr int RPP = NT / 8;           // tile rows staged per pass (8 lanes x 16 B per 128-B row)
+    static_assert(BC % RPP == 0 && BP % RPP == 0, "tile rows must be a multiple of the staging pass");
+    constexpr int WROWS = BC / RPP;       // staging rows per thread
+    constexpr int XROWS = BP / RPP;
+    constexpr int PASS_BYTES = NT * 16;
     constexpr int STAGE_BYTES = (BC + BP) * 128;
+    constexpr int LOADS_PER_STAGE = WROWS + XROWS;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -90,35 +126,64 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const ConvArgs a) {
     const int c0 = ct * BC;
     const int p0 = pt * BP;
 
-    // ---- staging geometry: thread -> (row = i*32 + srow, physical 16-B slot) ----
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // ---- epilogue operands fetched FIRST: the residual / bias latency hides under the K loop ----
+    u32x4 res_reg[MR / 2][NR];
+    f32x4 bias_lo[MR / 2], bias_hi[MR / 2];
+    const bool has_res = (a.res != nullptr);
+#pragma unroll
+    for (int t = 0; t < MR / 2; ++t) {
+        const int cout = c0 + wave_c * MR * 16 + 32 * t + 8 * fq;
+        bias_lo[t] = *reinterpret_cast<const f32x4*>(a.bias + cout);
+        bias_hi[t] = *reinterpret_cast<const f32x4*>(a.bias + cout + 4);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int m = p0 + (wave_p * NR + j) * 16 + fr;
+            u32x4 r = (u32x4){0u, 0u, 0u, 0u};
+            if (has_res && m < a.M) r = *reinterpret_cast<const u32x4*>(a.res + (size_t)m * a.Cout + cout);
+            res_reg[t][j] = r;
+        }
+    }
+
+    // ---- staging geometry: thread -> (row = i*RPP + srow, physical 16-B slot) ----
     const int srow = tid >> 3;
     const int slot = tid & 7;
     const int lchunk = slot ^ (srow & 7);          // logical K chunk this thread fetches
 
-    int x_pix0[XROWS], x_hi0[XROWS], x_wi0[XROWS];
+    const __amdgpu_buffer_rsrc_t rsrc_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w), 0, (unsigned)a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.x) - a.x_back), 0, (unsigned)a.x_records, 0x00020000);
+
+    unsigned x_voff[XROWS];                        // byte offset of the lane's chunk at the reference tap
+    unsigned x_mask[XROWS];                        // bit t set <=> tap t of this row is inside the image
 #pragma unroll
     for (int i = 0; i < XROWS; ++i) {
-        const int m = p0 + i * 32 + srow;
+        const int m = p0 + i * RPP + srow;
+        unsigned mask = 0u, voff = kOobOffset;
         if (m < a.M) {
             const int n = m / a.HoWo;
             const int r = m - n * a.HoWo;
             const int ho = r / a.Wo;
             const int wo = r - ho * a.Wo;
-            x_pix0[i] = n * a.H * a.W;
-            x_hi0[i] = ho * a.stride - a.pad;
-            x_wi0[i] = wo * a.stride - a.pad;
-        } else {
-            x_pix0[i] = 0;
-            x_hi0[i] = -(1 << 20);
-            x_wi0[i] = 0;
+            const int hc = ho * a.stride, wc = wo * a.stride;          // reference tap (pad,pad): always inside
+            voff = (unsigned)(((n * a.H + hc) * a.W + wc) * a.Cin + lchunk * 8) * 2u;
+            for (int dh = 0; dh < a.ks; ++dh)
+                for (int dw = 0; dw < a.ks; ++dw) {
+                    const int hi = hc - a.pad + dh, wi = wc - a.pad + dw;
+                    if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) mask |= 1u << (dh * a.ks + dw);
+                }
         }
+        x_voff[i] = voff;
+        x_mask[i] = mask;
     }
-    int w_off[WROWS];                              // element offset of (cout row, lchunk) at k = 0
+    unsigned w_voff[WROWS];
 #pragma unroll
     for (int i = 0; i < WROWS; ++i) {
-        const int rho = i * 32 + srow;             // LDS row
+        const int rho = i * RPP + srow;            // LDS row
         const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
-        w_off[i] = (c0 + cl) * a.Ktot + lchunk * 8;
+        w_voff[i] = (unsigned)((c0 + cl) * a.Ktot + lchunk * 8) * 2u;
     }
 
     f32x4 acc[MR][NR];
@@ -128,7 +193,6 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const ConvArgs a) {
         for (int j = 0; j < NR; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // fragment read addresses (bytes, relative to the stage's W / X base)
-    const int fr = lane & 15, fq = lane >> 4;
     const int fphys0 = (fq ^ (fr & 7)) << 4;       // kk = 0; kk = 1 is ^ 64
     const int w_frag = (wave_c * MR * 16 + fr) * 128;
     const int x_frag = BC * 128 + (wave_p * NR * 16 + fr) * 128;
@@ -136,104 +200,169 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const ConvArgs a) {
     u32x4 wreg[WROWS], xreg[XROWS];                // register staging only
     (void)wreg; (void)xreg;
 
-    int tap = 0, cc = 0;                           // K-step being staged
+    // scalar K-step state of the stage being ISSUED
+    int s_tap = 0, s_cc = 0, s_dw = 0;
+    int s_wofs = 0;                                // W soffset: step * 128
+    int s_tapofs = 0;                              // X soffset of the tap: (dh*W + dw)*Cin*2
+    const int row_adv = (a.W - a.ks) * a.Cin * 2;  // extra displacement when dw wraps to the next kernel row
+
+    bool ablate_first = true;
+    (void)ablate_first;
     auto stage_issue = [&](int buf) {
-        const int dh = tap / a.ks, dw = tap - dh * a.ks;
-        const int kofs = tap * a.Cin + cc * 64;
+#if R50_ABLATE == 1 || R50_ABLATE == 4 || R50_ABLATE == 5
+        if (!ablate_first) return;
+        ablate_first = false;
+#endif
         char* sbase = smem + buf * STAGE_BYTES;
+        const int xofs = s_tapofs + s_cc * 128;
 #pragma unroll
         for (int i = 0; i < WROWS; ++i) {
-            const __bf16* src = a.w + (size_t)(w_off[i] + kofs);
             if constexpr (GLDS) {
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src,
-                                                 (LDS_AS void*)(sbase + i * 4096 + wave * 1024), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (LDS_AS void*)(sbase + i * PASS_BYTES + wave * 1024), 16,
+                                                         w_voff[i], s_wofs, 0, 0);
             } else {
-                wreg[i] = *reinterpret_cast<const u32x4*>(src);
+                wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i], s_wofs, 0);
             }
         }
 #pragma unroll
         for (int i = 0; i < XROWS; ++i) {
-            const int hi = x_hi0[i] + dh, wi = x_wi0[i] + dw;
-            const bool ok = ((unsigned)hi < (unsigned)a.H) && ((unsigned)wi < (unsigned)a.W);
-            const size_t off = (size_t)(x_pix0[i] + hi * a.W + wi) * a.Cin + cc * 64 + lchunk * 8;
+            const unsigned voff = ((x_mask[i] >> s_tap) & 1u) ? x_voff[i] : kOobOffset;
             if constexpr (GLDS) {
-                const __bf16* src = ok ? (a.x + off) : (reinterpret_cast<const __bf16*>(a.zero) + lchunk * 8);
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src,
-                                                 (LDS_AS void*)(sbase + BC * 128 + i * 4096 + wave * 1024), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void*)(sbase + BC * 128 + i * PASS_BYTES + wave * 1024),
+                                                         16, voff, xofs, 0, 0);
             } else {
-                u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-                if (ok) v = *reinterpret_cast<const u32x4*>(a.x + off);
-                xreg[i] = v;
+                xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, voff, xofs, 0);
             }
         }
-        if (++cc == a.cin_chunks) { cc = 0; ++tap; }
+        s_wofs += 128;
+        if (++s_cc == a.cin_chunks) {
+            s_cc = 0;
+            ++s_tap;
+            s_tapofs += a.Cin * 2;
+            if (++s_dw == a.ks) { s_dw = 0; s_tapofs += row_adv; }
+        }
     };
     auto stage_write = [&](int buf) {              // register staging: regs -> LDS
         if constexpr (!GLDS) {
             char* sbase = smem + buf * STAGE_BYTES;
 #pragma unroll
             for (int i = 0; i < WROWS; ++i)
-                *reinterpret_cast<u32x4*>(sbase + i * 4096 + tid * 16) = wreg[i];
+                *reinterpret_cast<u32x4*>(sbase + i * PASS_BYTES + tid * 16) = wreg[i];
 #pragma unroll
             for (int i = 0; i < XROWS; ++i)
-                *reinterpret_cast<u32x4*>(sbase + BC * 128 + i * 4096 + tid * 16) = xreg[i];
+                *reinterpret_cast<u32x4*>(sbase + BC * 128 + i * PASS_BYTES + tid * 16) = xreg[i];
         }
     };
     auto compute = [&](int buf) {
+        // All 2*(MR+NR) fragment reads of the K-step are in flight early: the first half's, then the
+        // second half's slotted between the first half's MFMAs (pinned below).
         const char* sbase = smem + buf * STAGE_BYTES;
+#if R50_ABLATE == 3
+        asm volatile("" ::"v"(sbase));
+        return;
+#endif
+        bf16x8 wf[2][MR], xf[2][NR];
+#if R50_ABLATE == 4
+        {   // no LDS reads: opaque register garbage as fragments (timing only)
+            u32x4 g = (u32x4){(unsigned)tid, 0x3f803f80u, (unsigned)lane, 0x3f803f80u};
+            asm volatile("" : "+v"(g));
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) xf[kk][j] = __builtin_bit_cast(bf16x8, g);
+#pragma unroll
+                for (int m = 0; m < MR; ++m) wf[kk][m] = __builtin_bit_cast(bf16x8, g);
+            }
+            asm volatile("" ::"v"(sbase));
+        }
+#else
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int ph = fphys0 ^ (kk << 6);
-            bf16x8 wf[MR], xf[NR];
-#pragma unroll
-            for (int m = 0; m < MR; ++m)
-                wf[m] = *reinterpret_cast<const bf16x8*>(sbase + w_frag + m * 2048 + ph);
 #pragma unroll
             for (int j = 0; j < NR; ++j)
-                xf[j] = *reinterpret_cast<const bf16x8*>(sbase + x_frag + j * 2048 + ph);
+                xf[kk][j] = *reinterpret_cast<const bf16x8*>(sbase + x_frag + j * 2048 + ph);
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+                wf[kk][m] = *reinterpret_cast<const bf16x8*>(sbase + w_frag + m * 2048 + ph);
+        }
+#endif
+#if R50_ABLATE == 2
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m) asm volatile("" ::"v"(wf[kk][m]));
+#pragma unroll
+            for (int j = 0; j < NR; ++j) asm volatile("" ::"v"(xf[kk][j]));
+        }
+#else
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int m = 0; m < MR; ++m)
 #pragma unroll
                 for (int j = 0; j < NR; ++j)
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[j], acc[m][j], 0, 0, 0);
-        }
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][m], xf[kk][j], acc[m][j], 0, 0, 0);
+#endif
     };
 
-    // ---- main loop: 2 LDS stages, one barrier per K-step ----
-    stage_issue(0);
-    stage_write(0);
-    if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int buf = 0;
-    for (int k = 0; k < a.nk; ++k) {
-        const bool more = (k + 1 < a.nk);
-        if (more) stage_issue(buf ^ 1);
-        compute(buf);
-        if (more) stage_write(buf ^ 1);
+    if constexpr (MODE == IGEMM_GLDS3) {
+        // ---- 3 LDS stages; stage k+2 is issued right after the barrier that opens step k.  The wait
+        //      before that barrier leaves the newest stage's LOADS_PER_STAGE DMAs in flight.
+        //      RAW: own-wave vmcnt, then barrier, then ds_read.  WAR: buffer (k+2)%3 == (k-1)%3 was last
+        //      read in step k-1, which every wave finished before arriving at this barrier. ----
+        stage_issue(0);
+        if (a.nk > 1) stage_issue(1);
+        int buf = 0;
+        for (int k = 0; k < a.nk; ++k) {
+            if (k + 1 < a.nk) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_STAGE) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#if R50_ABLATE != 5
+            __builtin_amdgcn_s_barrier();
+#endif
+            if (k + 2 < a.nk) stage_issue(buf >= 1 ? buf - 1 : 2);      // (buf + 2) % 3
+            compute(buf);
+            buf = (buf == 2) ? 0 : buf + 1;
+        }
+    } else {
+        // ---- 2 LDS stages, one barrier per K-step ----
+        stage_issue(0);
+        stage_write(0);
         if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        buf ^= 1;
+        int buf = 0;
+        for (int k = 0; k < a.nk; ++k) {
+            const bool more = (k + 1 < a.nk);
+            if (more) stage_issue(buf ^ 1);
+            compute(buf);
+            if (more) stage_write(buf ^ 1);
+            if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if R50_ABLATE != 5
+            __syncthreads();
+#endif
+            buf ^= 1;
+        }
     }
 
     // ---- epilogue: + bias (+ residual) -> ReLU -> bf16 -> 16-B NHWC stores ----
 #pragma unroll
     for (int t = 0; t < MR / 2; ++t) {
         const int cout = c0 + wave_c * MR * 16 + 32 * t + 8 * fq;
-        const f32x4 b_lo = *reinterpret_cast<const f32x4*>(a.bias + cout);
-        const f32x4 b_hi = *reinterpret_cast<const f32x4*>(a.bias + cout + 4);
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int m = p0 + (wave_p * NR + j) * 16 + fr;
             if (m < a.M) {
-                const size_t o = (size_t)m * a.Cout + cout;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[2 * t][j][e] + b_lo[e];
-                    v[4 + e] = acc[2 * t + 1][j][e] + b_hi[e];
+                    v[e] = acc[2 * t][j][e] + bias_lo[t][e];
+                    v[4 + e] = acc[2 * t + 1][j][e] + bias_hi[t][e];
                 }
-                if (a.res != nullptr) {
-                    const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + o);
+                if (has_res) {
+                    const u32x4 r = res_reg[t][j];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[2 * e] += bf16_bits_to_f32(r[e] & 0xffffu);
@@ -247,10 +376,13 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const ConvArgs a) {
                 u32x4 out;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) out[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                *reinterpret_cast<u32x4*>(a.y + o) = out;
+                *reinterpret_cast<u32x4*>(a.y + (size_t)m * a.Cout + cout) = out;
             }
         }
     }
+#else
+    (void)a;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

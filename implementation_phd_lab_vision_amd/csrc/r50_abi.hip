@@ -154,54 +154,64 @@ void pack_stem(const float* wf, std::vector<uint16_t>& out) {
 // ---------------------------------------------------------------------------------------------
 // launches
 // ---------------------------------------------------------------------------------------------
-struct TileCfg { int id, bc, bp; };
-// id: 1 = 128c x 128p, 2 = 64c x 128p, 3 = 64c x 256p, 4 = 256c x 128p, 5 = 128c x 64p;
-// +16 = register staging instead of LDS-DMA.
+// Tile-config ids of igemm_bf16_kernel (BC couts x BP pixels):
+//   4 waves, 2 LDS stages (LDS-DMA; +16 = register staging): 1 = 128x128, 2 = 64x128, 3 = 64x256, 5 = 128x64
+//   8 waves, 3 LDS stages, counted vmcnt (MFMA-bound layers): 6 = 256x128, 7 = 128x256, 8 = 128x128,
+//                                                             9 = 256x64, 10 = 64x256
 constexpr int kRegStageBit = 16;
 
-template <int BC, int BP, int WC, int WP, bool G>
+template <int BC, int BP, int WC, int WP, int MODE>
 hipError_t launch_igemm_t(ConvArgs a, hipStream_t s) {
     a.n_ctiles = a.Cout / BC;
     a.n_blocks = a.n_ctiles * ((a.M + BP - 1) / BP);
-    constexpr size_t lds = 2 * (BC + BP) * 128;
-    auto kern = igemm_bf16_kernel<BC, BP, WC, WP, G>;
+    const int stages = (MODE == IGEMM_GLDS3) ? 3 : (a.nk > 1 ? 2 : 1);
+    const size_t lds = (size_t)stages * (BC + BP) * 128;
+    auto kern = igemm_bf16_kernel<BC, BP, WC, WP, MODE>;
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(WC * WP * 64), lds, s, a);
     return hipGetLastError();
 }
 
-int auto_tile(int cout, int M) {
-    if (cout % 128) return (M >= 256 * 512) ? 3 : 2;
-    if (M < 128 * 96) return 5;   // few pixel tiles: halve BP to fill the CUs
+int auto_tile(const ConvArgs& a) {
+    if (a.Cout % 128) return 2;
+    if (a.res != nullptr) return 5;
     return 1;
 }
 
 hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s) {
-    if (tile == 0) tile = auto_tile(a.Cout, a.M);
-    const bool glds = !(tile & kRegStageBit);
+    if (tile == 0) tile = auto_tile(a);
+    const bool reg = (tile & kRegStageBit) != 0;
     const int id = tile & (kRegStageBit - 1);
-#define R50_DISPATCH(BC, BP, WC, WP)                                                      \
-    return glds ? launch_igemm_t<BC, BP, WC, WP, true>(a, s) : launch_igemm_t<BC, BP, WC, WP, false>(a, s)
+#define R50_DISPATCH2(BC, BP, WC, WP)                                                     \
+    return reg ? launch_igemm_t<BC, BP, WC, WP, IGEMM_REG2>(a, s) : launch_igemm_t<BC, BP, WC, WP, IGEMM_GLDS2>(a, s)
+#define R50_DISPATCH3(BC, BP, WC, WP)                                                     \
+    if (reg) return hipErrorInvalidValue;                                                 \
+    return launch_igemm_t<BC, BP, WC, WP, IGEMM_GLDS3>(a, s)
     switch (id) {
-        case 1: if (a.Cout % 128) return hipErrorInvalidValue; R50_DISPATCH(128, 128, 2, 2);
-        case 2: R50_DISPATCH(64, 128, 1, 4);
-        case 3: R50_DISPATCH(64, 256, 1, 4);
-        case 4: if (a.Cout % 256) return hipErrorInvalidValue; R50_DISPATCH(256, 128, 4, 1);
-        case 5: if (a.Cout % 128) return hipErrorInvalidValue; R50_DISPATCH(128, 64, 2, 2);
+        case 1: if (a.Cout % 128) return hipErrorInvalidValue; R50_DISPATCH2(128, 128, 2, 2);
+        case 2: R50_DISPATCH2(64, 128, 1, 4);
+        case 3: R50_DISPATCH2(64, 256, 1, 4);
+        case 5: if (a.Cout % 128) return hipErrorInvalidValue; R50_DISPATCH2(128, 64, 2, 2);
+        case 6: if (a.Cout % 256) return hipErrorInvalidValue; R50_DISPATCH3(256, 128, 4, 2);
+        case 7: if (a.Cout % 128) return hipErrorInvalidValue; R50_DISPATCH3(128, 256, 2, 4);
+        case 8: if (a.Cout % 128) return hipErrorInvalidValue; R50_DISPATCH3(128, 128, 2, 4);
+        case 9: if (a.Cout % 256) return hipErrorInvalidValue; R50_DISPATCH3(256, 64, 4, 2);
+        case 10: R50_DISPATCH3(64, 256, 1, 8);
         default: return hipErrorInvalidValue;
     }
-#undef R50_DISPATCH
+#undef R50_DISPATCH2
+#undef R50_DISPATCH3
 }
 
 int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, const void* wt, const float* bias,
                    const void* res, void* y, int cout, int ks, int stride, int pad, int relu, const void* zero) {
     if (!x || !wt || !bias || !y || !zero) return R50_ERR_INVALID;
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cin % 64 || cout <= 0 || cout % 64) return R50_ERR_INVALID;
-    if (!(ks == 1 || ks == 3) || stride < 1 || pad < 0 || pad >= ks) return R50_ERR_INVALID;
+    if (!(ks == 1 || ks == 3) || stride < 1 || pad < 0 || 2 * pad > ks - 1) return R50_ERR_INVALID;
     a.x = (const __bf16*)x; a.w = (const __bf16*)wt; a.bias = bias; a.res = (const __bf16*)res; a.y = (__bf16*)y;
     a.zero = zero;
     a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;
@@ -216,6 +226,12 @@ int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, con
     a.M = (int)M; a.HoWo = a.Ho * a.Wo;
     a.cin_chunks = cin / 64; a.nk = ks * ks * a.cin_chunks; a.Ktot = ks * ks * cin;
     a.n_ctiles = 0; a.n_blocks = 0;
+    // buffer descriptors of the kernel (kernels.h): every offset must stay below 2^31
+    const long long x_bytes = (long long)n * h * w * cin * 2;
+    a.x_back = (pad * w + pad) * cin * 2;
+    if (x_bytes + a.x_back >= (1ll << 31) || (long long)cout * a.Ktot * 2 >= (1ll << 31)) return R50_ERR_INVALID;
+    a.x_records = (unsigned)(x_bytes + a.x_back);
+    a.w_bytes = (unsigned)((long long)cout * a.Ktot * 2);
     return R50_OK;
 }
 

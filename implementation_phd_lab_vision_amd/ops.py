@@ -17,9 +17,13 @@ TILE_AUTO = 0
 TILE_128x128 = 1
 TILE_64x128 = 2
 TILE_64x256 = 3
-TILE_256x128 = 4
 TILE_128x64 = 5
-REG_STAGE = 16
+TILE_256x128_P3 = 6      # 8 waves, 3 LDS stages, counted vmcnt
+TILE_128x256_P3 = 7
+TILE_128x128_P3 = 8
+TILE_256x64_P3 = 9
+TILE_64x256_P3 = 10
+REG_STAGE = 16           # + REG_STAGE on the 2-stage tiles: register staging instead of LDS-DMA
 
 
 def _stream(t: torch.Tensor) -> int:

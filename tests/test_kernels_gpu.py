@@ -55,11 +55,11 @@ CONV_CASES = [
 
 def _tiles_for(cout):
     from implementation_phd_lab_vision_amd import ops
-    t = [ops.TILE_AUTO, ops.TILE_64x128, ops.TILE_64x256]
+    t = [ops.TILE_AUTO, ops.TILE_64x128, ops.TILE_64x256, ops.TILE_64x256_P3]
     if cout % 128 == 0:
-        t += [ops.TILE_128x128, ops.TILE_128x64]
+        t += [ops.TILE_128x128, ops.TILE_128x64, ops.TILE_128x256_P3, ops.TILE_128x128_P3]
     if cout % 256 == 0:
-        t += [ops.TILE_256x128]
+        t += [ops.TILE_256x128_P3, ops.TILE_256x64_P3]
     return t
 
 
@@ -84,7 +84,7 @@ def test_conv2d_matches_oracle(lib_built, case):
     rd = res.permute(0, 2, 3, 1).contiguous().to(d) if has_res else None
     for tile in _tiles_for(cout):
         for stage in (0, ops.REG_STAGE):
-            if tile == ops.TILE_AUTO and stage:
+            if stage and (tile == ops.TILE_AUTO or tile >= ops.TILE_256x128_P3):
                 continue
             y = ops.conv2d_bf16(xd, wd, bd, stride=stride, pad=pad, relu=relu, residual=rd, tile=tile | stage)
             torch.cuda.synchronize()
@@ -99,8 +99,11 @@ def test_conv2d_identity_asymmetric(lib_built):
     n, h, w, c = 2, 6, 5, 128
     x = torch.arange(n * h * w * c, dtype=torch.float32).remainder(251.0).sub(125.0).view(n, h, w, c).to(torch.bfloat16)
     wt = torch.eye(c).view(c, 1, 1, c).to(torch.bfloat16)
-    for tile in (ops.TILE_64x128, ops.TILE_128x128, ops.TILE_128x64, ops.TILE_64x256):
+    for tile in (ops.TILE_64x128, ops.TILE_128x128, ops.TILE_128x64, ops.TILE_64x256, ops.TILE_128x256_P3,
+                 ops.TILE_128x128_P3, ops.TILE_64x256_P3):
         for stage in (0, ops.REG_STAGE):
+            if stage and tile >= ops.TILE_256x128_P3:
+                continue
             y = ops.conv2d_bf16(x.to(d), wt.to(d), torch.zeros(c, device=d), relu=False, tile=tile | stage)
             assert torch.equal(y.cpu(), x), f"identity conv mismatch, tile {tile} stage {stage}"
 
