@@ -29,26 +29,50 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Implicit-GEMM convolution (k = 1 or 3, any stride/pad), fused folded-BN bias + residual + ReLU.
+// Implicit-GEMM convolution (k = 1 or 3, stride 1 or 2), fused folded-BN bias + residual + ReLU.
 //
 // GEMM view:  Y[cout][pixel] = sum_k Wt[cout][k] * X[k][pixel],  k = (tap, cin), BK = 64 per step.
-// Workgroup tile BC couts x BP pixels, 256 threads = WC x WP waves.  LDS image per operand is
+// Workgroup tile BC couts x BP pixels, WC x WP waves (4 or 8).  LDS image per operand is
 // [rows][128 B] (one row = 64 bf16 of K), 16-B chunk c of row r stored at chunk c ^ (r & 7)
-// (conflict-free ds_read_b128 for MFMA fragments).  Staging is either LDS-DMA
-// (global_load_lds_dwordx4: destination is lane-linear, so the XOR is applied to the per-lane
-// SOURCE address) or register staging (global_load_dwordx4 + ds_write_b128).
-// Padding pixels and the M tail read from a 128-B zero page.
+// (conflict-free ds_read_b128 for MFMA fragments).  Staging is LDS-DMA (buffer_load_dwordx4 ... lds:
+// the destination is lane-linear, so the XOR is applied to the per-lane SOURCE offset).
 // Output-channel order inside each 32-row group of the W tile is permuted at staging time so that
 // lane (q = lane>>4) of MFMA block pair (2t, 2t+1) ends up with channels 32t + 8q .. +7: one 16-B
 // NHWC store per pixel.
+//
+// Addressing keeps vector-ALU work out of the K loop and the epilogue: every global access is a
+// buffer instruction = SRD base + per-lane voffset (fixed per tile) + scalar soffset.
+//   W: voffset = (cout_row * Ktot + chunk*8) * 2,  soffset = step * 128.
+//   X: voffset = byte offset of the lane's pixel at the REFERENCE tap (pad,pad) -- always inside
+//      the image -- and soffset = ((dh*W + dw)*Cin + cc*64) * 2 against an SRD base moved back by
+//      (pad*W + pad)*Cin*2 bytes, so every component is non-negative.  A lane whose tap falls in the
+//      padding (or whose row is past M) uses voffset = 2^31 >= num_records: the buffer range check
+//      returns zeros for it (activation bytes < 2^31, checked on the host).
+//   Y / residual: voffset = ((tile_pixel0 + lane_pixel + 16*j) * Cout + lane_cout + 32*t) * 2; rows
+//      past M are dropped by the range check (num_records = M*Cout*2).  The range check looks at
+//      voffset (+ immediate) only, never at soffset: anything that must be checked lives in voffset.
+//
+// The kernel is PERSISTENT-capable: workgroup b walks tiles b', b' + grid, ... and treats its (tile,
+// K-step) pairs as one stream through the LDS stage ring, so tile t+1's first K-steps are in flight
+// while tile t finishes and tile t's stores drain under tile t+1's MFMAs.  grid = #tiles gives the
+// one-tile-per-workgroup form.  NSTAGE = 2 (4 waves, several workgroups per CU) or 3 (8 waves,
+// counted vmcnt: two K-steps of DMA in flight).  Per stream step g (D = NSTAGE-1):
+//     s_waitcnt vmcnt((D-1)*LOADS)  own DMAs of step g landed (other vector-memory ops in between are
+//                                   ordered by issue, so they can only make the wait stricter)
+//     s_barrier                     RAW: everybody's DMAs of step g landed;  WAR: everybody finished
+//                                   reading the buffer that step g+D overwrites
+//     issue DMAs of step g+D ; ds_read + MFMA of step g ; [epilogue of a finished tile]
 // ------------------------------------------------------------------------------------------------
+struct FastDiv {          // n / d for n < 2^31: d == 1 -> mul == 0;  else (umulhi(n, mul) >> shr)
+    unsigned mul, shr;
+};
+
 struct ConvArgs {
     const __bf16* x;      // (N,H,W,Cin)
     const __bf16* w;      // (Cout, taps, Cin)   K-major
     const float* bias;    // (Cout)
     const __bf16* res;    // (N,Ho,Wo,Cout) or nullptr
     __bf16* y;            // (N,Ho,Wo,Cout)
-    const void* zero;     // >= 128 B of zeros
     int N, H, W, Cin, Ho, Wo, Cout;
     int ks, stride, pad, relu;
     int M;                // N*Ho*Wo
@@ -57,54 +81,43 @@ struct ConvArgs {
     int nk;               // ks*ks*cin_chunks
     int Ktot;             // ks*ks*Cin
     int n_ctiles;         // Cout / BC
-    int n_blocks;
+    int n_blocks;         // tiles
     int x_back;           // bytes the X descriptor base sits before x: (pad*W + pad)*Cin*2
     unsigned x_records;   // X descriptor size: activation bytes + x_back (< 2^31)
     unsigned w_bytes;     // W descriptor size
+    unsigned y_bytes;     // Y / residual descriptor size: M*Cout*2
+    FastDiv div_howo, div_wo, div_ctiles;
 };
+
+__device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv d) {
+    return d.mul == 0u ? n : (__umulhi(n, d.mul) >> d.shr);
+}
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     // Blocks b and b+8 share an XCD (observed round-robin; speed only, never correctness).  Give each
-    // XCD a contiguous run of logical tile ids so tiles sharing an X panel hit the same L2.
+    // XCD a contiguous run of logical ids so tiles sharing an X panel hit the same L2.
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (bid >> 3);
 }
 
-// MODE: 0 = LDS-DMA staging, 2 LDS stages, one barrier per K-step (vmcnt(0) before it);
-//       1 = register staging (buffer_load_dwordx4 -> ds_write_b128), 2 LDS stages;
-//       2 = LDS-DMA staging, 3 LDS stages, raw s_barrier + COUNTED vmcnt: two K-steps of loads stay in
-//           flight across the barrier (one workgroup of 8 waves per CU).
-//
-// Addressing (the K loop carries almost no vector ALU work): both operands are fetched with
-// buffer_load_dwordx4 [... lds]: address = SRD base + per-lane voffset (fixed for the whole kernel)
-// + scalar soffset (the K-step's uniform displacement).
-//   W: voffset = (cout_row * Ktot + chunk*8) * 2,  soffset = step * 128.
-//   X: voffset = byte offset of the lane's pixel at the REFERENCE tap (pad,pad) -- always inside
-//      the image -- and soffset = ((dh*W + dw)*Cin + cc*64) * 2 against an SRD base moved back by
-//      (pad*W + pad)*Cin*2 bytes, so every component is non-negative.  A lane whose tap falls in the
-//      padding (or whose row is past M) uses voffset = 2^31 >= num_records: the buffer range check
-//      returns zeros for it (requires activation bytes < 2^31, checked on the host).
-enum { IGEMM_GLDS2 = 0, IGEMM_REG2 = 1, IGEMM_GLDS3 = 2 };
-
-// Diagnostic builds only (scripts/ablate.sh): R50_ABLATE = 1 no global loads inside the K loop,
-// 2 = no MFMAs (fragment reads kept alive), 3 = no fragment reads and no MFMAs (fill rate only).
-#ifndef R50_ABLATE
-#define R50_ABLATE 0
-#endif
+__device__ __forceinline__ unsigned relu_bf16x2(unsigned v) {   // max(x, 0) on two packed bf16 = v_pk_max_i16
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+}
 
 constexpr unsigned kOobOffset = 0x80000000u;
 
-template <int BC, int BP, int WC, int WP, int MODE>
+template <int BC, int BP, int WC, int WP, int NSTAGE>
 __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body only in the device pass: the host pass needs just the launch stub
                                       // (the LDS-DMA buffer builtin has no host-side lowering)
-    constexpr int NT = WC * WP * 64;      // threads per workgroup
-    constexpr bool GLDS = (MODE != IGEMM_REG2);
-    constexpr int NSTAGE = (MODE == IGEMM_GLDS3) ? 3 : 2;
+    constexpr int NT = WC * WP * 64;
     constexpr int MR = BC / WC / 16;      // cout blocks per wave
     constexpr int NR = BP / WP / 16;      // pixel blocks per wave
     static_assert(MR >= 2 && (MR % 2) == 0, "wave needs >= 32 couts");
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "2 or 3 LDS stages");
     constexpr int RPP = NT / 8;           // tile rows staged per pass (8 lanes x 16 B per 128-B row)
     static_assert(BC % RPP == 0 && BP % RPP == 0, "tile rows must be a multiple of the staging pass");
     constexpr int WROWS = BC / RPP;       // staging rows per thread
@@ -112,6 +125,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
     constexpr int PASS_BYTES = NT * 16;
     constexpr int STAGE_BYTES = (BC + BP) * 128;
     constexpr int LOADS_PER_STAGE = WROWS + XROWS;
+    constexpr int D = NSTAGE - 1;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -119,163 +133,123 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_c = wave / WP, wave_p = wave % WP;
-
-    const int tile = xcd_remap(blockIdx.x, a.n_blocks);
-    const int ct = tile % a.n_ctiles;
-    const int pt = tile / a.n_ctiles;
-    const int c0 = ct * BC;
-    const int p0 = pt * BP;
-
     const int fr = lane & 15, fq = lane >> 4;
-
-    // ---- epilogue operands fetched FIRST: the residual / bias latency hides under the K loop ----
-    u32x4 res_reg[MR / 2][NR];
-    f32x4 bias_lo[MR / 2], bias_hi[MR / 2];
-    const bool has_res = (a.res != nullptr);
-#pragma unroll
-    for (int t = 0; t < MR / 2; ++t) {
-        const int cout = c0 + wave_c * MR * 16 + 32 * t + 8 * fq;
-        bias_lo[t] = *reinterpret_cast<const f32x4*>(a.bias + cout);
-        bias_hi[t] = *reinterpret_cast<const f32x4*>(a.bias + cout + 4);
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const int m = p0 + (wave_p * NR + j) * 16 + fr;
-            u32x4 r = (u32x4){0u, 0u, 0u, 0u};
-            if (has_res && m < a.M) r = *reinterpret_cast<const u32x4*>(a.res + (size_t)m * a.Cout + cout);
-            res_reg[t][j] = r;
-        }
-    }
-
-    // ---- staging geometry: thread -> (row = i*RPP + srow, physical 16-B slot) ----
     const int srow = tid >> 3;
     const int slot = tid & 7;
     const int lchunk = slot ^ (srow & 7);          // logical K chunk this thread fetches
 
+    const int grid = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, grid);
+    const int my_tiles = (a.n_blocks - first + grid - 1) / grid;      // >= 1 (grid <= n_blocks)
+    const int total = my_tiles * a.nk;
+
     const __amdgpu_buffer_rsrc_t rsrc_w =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w), 0, (unsigned)a.w_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w), 0, a.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(a.x) - a.x_back), 0, (unsigned)a.x_records, 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(a.x) - a.x_back), 0, a.x_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, a.res ? a.y_bytes : 0u, 0x00020000);
 
-    unsigned x_voff[XROWS];                        // byte offset of the lane's chunk at the reference tap
-    unsigned x_mask[XROWS];                        // bit t set <=> tap t of this row is inside the image
+    // ---------------- issue side: geometry of the tile whose K-steps are being fetched --------------
+    unsigned x_voff[XROWS], x_mask[XROWS], w_voff[WROWS];
+    auto decode_tile = [&](int tile) {
+        const int pt = (int)fast_div((unsigned)tile, a.div_ctiles);
+        const int ct = tile - pt * a.n_ctiles;
+        const int c0 = ct * BC, p0 = pt * BP;
 #pragma unroll
-    for (int i = 0; i < XROWS; ++i) {
-        const int m = p0 + i * RPP + srow;
-        unsigned mask = 0u, voff = kOobOffset;
-        if (m < a.M) {
-            const int n = m / a.HoWo;
-            const int r = m - n * a.HoWo;
-            const int ho = r / a.Wo;
-            const int wo = r - ho * a.Wo;
-            const int hc = ho * a.stride, wc = wo * a.stride;          // reference tap (pad,pad): always inside
-            voff = (unsigned)(((n * a.H + hc) * a.W + wc) * a.Cin + lchunk * 8) * 2u;
-            for (int dh = 0; dh < a.ks; ++dh)
-                for (int dw = 0; dw < a.ks; ++dw) {
-                    const int hi = hc - a.pad + dh, wi = wc - a.pad + dw;
-                    if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) mask |= 1u << (dh * a.ks + dw);
+        for (int i = 0; i < XROWS; ++i) {
+            const int m = p0 + i * RPP + srow;
+            unsigned mask = 0u, voff = kOobOffset;
+            if (m < a.M) {
+                const int n = (int)fast_div((unsigned)m, a.div_howo);
+                const int r = m - n * a.HoWo;
+                const int ho = (int)fast_div((unsigned)r, a.div_wo);
+                const int wo = r - ho * a.Wo;
+                const int hc = ho * a.stride, wc = wo * a.stride;          // reference tap (pad,pad): always inside
+                voff = (unsigned)(((n * a.H + hc) * a.W + wc) * a.Cin + lchunk * 8) * 2u;
+                if (a.ks == 1) {
+                    mask = 1u;
+                } else {                                                    // ks == 3: bit (dh*3 + dw)
+                    const unsigned hm = (hc >= a.pad ? 1u : 0u) | 2u | (hc - a.pad + 2 < a.H ? 4u : 0u);
+                    const unsigned wm = (wc >= a.pad ? 1u : 0u) | 2u | (wc - a.pad + 2 < a.W ? 4u : 0u);
+                    mask = ((hm & 1u) ? wm : 0u) | ((hm & 2u) ? (wm << 3) : 0u) | ((hm & 4u) ? (wm << 6) : 0u);
                 }
+            }
+            x_voff[i] = voff;
+            x_mask[i] = mask;
         }
-        x_voff[i] = voff;
-        x_mask[i] = mask;
-    }
-    unsigned w_voff[WROWS];
 #pragma unroll
-    for (int i = 0; i < WROWS; ++i) {
-        const int rho = i * RPP + srow;            // LDS row
-        const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
-        w_voff[i] = (unsigned)((c0 + cl) * a.Ktot + lchunk * 8) * 2u;
-    }
+        for (int i = 0; i < WROWS; ++i) {
+            const int rho = i * RPP + srow;            // LDS row -> channel (permuted inside 32-row groups)
+            const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+            w_voff[i] = (unsigned)((c0 + cl) * a.Ktot + lchunk * 8) * 2u;
+        }
+    };
+    int i_tile = first, i_k = 0, i_tap = 0, i_cc = 0, i_dw = 0, i_wofs = 0, i_tapofs = 0, i_buf = 0;
+    const int row_adv = (a.W - a.ks) * a.Cin * 2;  // extra displacement when dw wraps to the next kernel row
+    decode_tile(i_tile);
+    auto stage_issue = [&]() {
+        char* sbase = smem + i_buf * STAGE_BYTES;
+        const int xofs = i_tapofs + i_cc * 128;
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (LDS_AS void*)(sbase + i * PASS_BYTES + wave * 1024), 16,
+                                                     w_voff[i], i_wofs, 0, 0);
+#pragma unroll
+        for (int i = 0; i < XROWS; ++i) {
+            const unsigned voff = ((x_mask[i] >> i_tap) & 1u) ? x_voff[i] : kOobOffset;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void*)(sbase + BC * 128 + i * PASS_BYTES + wave * 1024),
+                                                     16, voff, xofs, 0, 0);
+        }
+        i_buf = (i_buf == NSTAGE - 1) ? 0 : i_buf + 1;
+        i_wofs += 128;
+        if (++i_cc == a.cin_chunks) {
+            i_cc = 0;
+            ++i_tap;
+            i_tapofs += a.Cin * 2;
+            if (++i_dw == a.ks) { i_dw = 0; i_tapofs += row_adv; }
+        }
+        if (++i_k == a.nk) {                       // next tile of this workgroup's stream
+            i_k = 0; i_tap = 0; i_cc = 0; i_dw = 0; i_wofs = 0; i_tapofs = 0;
+            i_tile += grid;
+            if (i_tile < a.n_blocks) decode_tile(i_tile);
+        }
+    };
 
+    // ---------------- compute side ----------------------------------------------------------------
     f32x4 acc[MR][NR];
-#pragma unroll
-    for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int j = 0; j < NR; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // fragment read addresses (bytes, relative to the stage's W / X base)
+    u32x4 res_reg[MR / 2][NR];
+    const bool has_res = (a.res != nullptr);
     const int fphys0 = (fq ^ (fr & 7)) << 4;       // kk = 0; kk = 1 is ^ 64
     const int w_frag = (wave_c * MR * 16 + fr) * 128;
     const int x_frag = BC * 128 + (wave_p * NR * 16 + fr) * 128;
+    const int cout_lane = wave_c * MR * 16 + 8 * fq;
+    const int pix_lane = wave_p * NR * 16 + fr;
+    int c_tile = first, c_k = 0, c_buf = 0;
+    unsigned y_voff = 0u;                          // byte offset of (tile pixel0 + lane pixel, tile cout0 + lane cout)
+    const unsigned y_rowstep = (unsigned)(16 * a.Cout * 2);   // 16 pixels further (next pixel block of the wave)
 
-    u32x4 wreg[WROWS], xreg[XROWS];                // register staging only
-    (void)wreg; (void)xreg;
-
-    // scalar K-step state of the stage being ISSUED
-    int s_tap = 0, s_cc = 0, s_dw = 0;
-    int s_wofs = 0;                                // W soffset: step * 128
-    int s_tapofs = 0;                              // X soffset of the tap: (dh*W + dw)*Cin*2
-    const int row_adv = (a.W - a.ks) * a.Cin * 2;  // extra displacement when dw wraps to the next kernel row
-
-    bool ablate_first = true;
-    (void)ablate_first;
-    auto stage_issue = [&](int buf) {
-#if R50_ABLATE == 1 || R50_ABLATE == 4 || R50_ABLATE == 5
-        if (!ablate_first) return;
-        ablate_first = false;
-#endif
-        char* sbase = smem + buf * STAGE_BYTES;
-        const int xofs = s_tapofs + s_cc * 128;
+    auto tile_begin = [&]() {                      // accumulators start at the bias; residual fetched early
+        const int pt = (int)fast_div((unsigned)c_tile, a.div_ctiles);
+        const int c0 = (c_tile - pt * a.n_ctiles) * BC, p0 = pt * BP;
+        y_voff = (unsigned)((p0 + pix_lane) * a.Cout + c0 + cout_lane) * 2u;
 #pragma unroll
-        for (int i = 0; i < WROWS; ++i) {
-            if constexpr (GLDS) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (LDS_AS void*)(sbase + i * PASS_BYTES + wave * 1024), 16,
-                                                         w_voff[i], s_wofs, 0, 0);
-            } else {
-                wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[i], s_wofs, 0);
+        for (int t = 0; t < MR / 2; ++t) {
+            const f32x4 b_lo = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t);
+            const f32x4 b_hi = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t + 4);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                acc[2 * t][j] = b_lo;
+                acc[2 * t + 1][j] = b_hi;
+                if (has_res)     // row displacement in voffset: soffset is not part of the range check
+                    res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, 0);
             }
         }
-#pragma unroll
-        for (int i = 0; i < XROWS; ++i) {
-            const unsigned voff = ((x_mask[i] >> s_tap) & 1u) ? x_voff[i] : kOobOffset;
-            if constexpr (GLDS) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void*)(sbase + BC * 128 + i * PASS_BYTES + wave * 1024),
-                                                         16, voff, xofs, 0, 0);
-            } else {
-                xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, voff, xofs, 0);
-            }
-        }
-        s_wofs += 128;
-        if (++s_cc == a.cin_chunks) {
-            s_cc = 0;
-            ++s_tap;
-            s_tapofs += a.Cin * 2;
-            if (++s_dw == a.ks) { s_dw = 0; s_tapofs += row_adv; }
-        }
     };
-    auto stage_write = [&](int buf) {              // register staging: regs -> LDS
-        if constexpr (!GLDS) {
-            char* sbase = smem + buf * STAGE_BYTES;
-#pragma unroll
-            for (int i = 0; i < WROWS; ++i)
-                *reinterpret_cast<u32x4*>(sbase + i * PASS_BYTES + tid * 16) = wreg[i];
-#pragma unroll
-            for (int i = 0; i < XROWS; ++i)
-                *reinterpret_cast<u32x4*>(sbase + BC * 128 + i * PASS_BYTES + tid * 16) = xreg[i];
-        }
-    };
-    auto compute = [&](int buf) {
-        // All 2*(MR+NR) fragment reads of the K-step are in flight early: the first half's, then the
-        // second half's slotted between the first half's MFMAs (pinned below).
-        const char* sbase = smem + buf * STAGE_BYTES;
-#if R50_ABLATE == 3
-        asm volatile("" ::"v"(sbase));
-        return;
-#endif
+    auto compute = [&]() {
+        const char* sbase = smem + c_buf * STAGE_BYTES;
         bf16x8 wf[2][MR], xf[2][NR];
-#if R50_ABLATE == 4
-        {   // no LDS reads: opaque register garbage as fragments (timing only)
-            u32x4 g = (u32x4){(unsigned)tid, 0x3f803f80u, (unsigned)lane, 0x3f803f80u};
-            asm volatile("" : "+v"(g));
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                for (int j = 0; j < NR; ++j) xf[kk][j] = __builtin_bit_cast(bf16x8, g);
-#pragma unroll
-                for (int m = 0; m < MR; ++m) wf[kk][m] = __builtin_bit_cast(bf16x8, g);
-            }
-            asm volatile("" ::"v"(sbase));
-        }
-#else
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int ph = fphys0 ^ (kk << 6);
@@ -286,16 +260,6 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
             for (int m = 0; m < MR; ++m)
                 wf[kk][m] = *reinterpret_cast<const bf16x8*>(sbase + w_frag + m * 2048 + ph);
         }
-#endif
-#if R50_ABLATE == 2
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int m = 0; m < MR; ++m) asm volatile("" ::"v"(wf[kk][m]));
-#pragma unroll
-            for (int j = 0; j < NR; ++j) asm volatile("" ::"v"(xf[kk][j]));
-        }
-#else
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -303,81 +267,50 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
 #pragma unroll
                 for (int j = 0; j < NR; ++j)
                     acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][m], xf[kk][j], acc[m][j], 0, 0, 0);
-#endif
     };
-
-    if constexpr (MODE == IGEMM_GLDS3) {
-        // ---- 3 LDS stages; stage k+2 is issued right after the barrier that opens step k.  The wait
-        //      before that barrier leaves the newest stage's LOADS_PER_STAGE DMAs in flight.
-        //      RAW: own-wave vmcnt, then barrier, then ds_read.  WAR: buffer (k+2)%3 == (k-1)%3 was last
-        //      read in step k-1, which every wave finished before arriving at this barrier. ----
-        stage_issue(0);
-        if (a.nk > 1) stage_issue(1);
-        int buf = 0;
-        for (int k = 0; k < a.nk; ++k) {
-            if (k + 1 < a.nk) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_STAGE) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-#if R50_ABLATE != 5
-            __builtin_amdgcn_s_barrier();
-#endif
-            if (k + 2 < a.nk) stage_issue(buf >= 1 ? buf - 1 : 2);      // (buf + 2) % 3
-            compute(buf);
-            buf = (buf == 2) ? 0 : buf + 1;
-        }
-    } else {
-        // ---- 2 LDS stages, one barrier per K-step ----
-        stage_issue(0);
-        stage_write(0);
-        if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int buf = 0;
-        for (int k = 0; k < a.nk; ++k) {
-            const bool more = (k + 1 < a.nk);
-            if (more) stage_issue(buf ^ 1);
-            compute(buf);
-            if (more) stage_write(buf ^ 1);
-            if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if R50_ABLATE != 5
-            __syncthreads();
-#endif
-            buf ^= 1;
-        }
-    }
-
-    // ---- epilogue: + bias (+ residual) -> ReLU -> bf16 -> 16-B NHWC stores ----
+    auto epilogue = [&]() {                        // (+ residual) -> bf16 -> ReLU on the packed pair -> 16-B store
 #pragma unroll
-    for (int t = 0; t < MR / 2; ++t) {
-        const int cout = c0 + wave_c * MR * 16 + 32 * t + 8 * fq;
+        for (int t = 0; t < MR / 2; ++t) {
 #pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const int m = p0 + (wave_p * NR + j) * 16 + fr;
-            if (m < a.M) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[2 * t][j][e] + bias_lo[t][e];
-                    v[4 + e] = acc[2 * t + 1][j][e] + bias_hi[t][e];
-                }
+            for (int j = 0; j < NR; ++j) {
+                f32x4 lo = acc[2 * t][j], hi = acc[2 * t + 1][j];
                 if (has_res) {
                     const u32x4 r = res_reg[t][j];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += bf16_bits_to_f32(r[e] & 0xffffu);
-                        v[2 * e + 1] += bf16_bits_to_f32(r[e] >> 16);
-                    }
+                    lo[0] += bf16_bits_to_f32(r[0] & 0xffffu); lo[1] += __uint_as_float(r[0] & 0xffff0000u);
+                    lo[2] += bf16_bits_to_f32(r[1] & 0xffffu); lo[3] += __uint_as_float(r[1] & 0xffff0000u);
+                    hi[0] += bf16_bits_to_f32(r[2] & 0xffffu); hi[1] += __uint_as_float(r[2] & 0xffff0000u);
+                    hi[2] += bf16_bits_to_f32(r[3] & 0xffffu); hi[3] += __uint_as_float(r[3] & 0xffff0000u);
                 }
+                u32x4 out = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                                    pack_bf16x2(hi[2], hi[3])};
                 if (a.relu) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 4; ++e) out[e] = relu_bf16x2(out[e]);
                 }
-                u32x4 out;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) out[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                *reinterpret_cast<u32x4*>(a.y + (size_t)m * a.Cout + cout) = out;
+                __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, y_voff + j * y_rowstep + 64 * t, 0, 0);
             }
+        }
+    };
+
+    // ---------------- the stream ------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < total) stage_issue();
+    for (int g = 0; g < total; ++g) {
+        if (NSTAGE == 3 && g + 1 < total) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_STAGE) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (c_k == 0) tile_begin();
+        if (g + D < total) stage_issue();
+        compute();
+        c_buf = (c_buf == NSTAGE - 1) ? 0 : c_buf + 1;
+        if (++c_k == a.nk) {
+            epilogue();
+            c_k = 0;
+            c_tile += grid;
         }
     }
 #else

@@ -52,7 +52,6 @@ struct r50_handle {
     char* stem_w = nullptr;             // packed stem weights (device)
     char* stem_xp = nullptr;            // packed input image (device)
     __bf16* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    void* zero = nullptr;
     size_t buf_bytes = 0;
     Prof prof[PC_COUNT];
     std::vector<EvRec> ev_pending;
@@ -151,69 +150,108 @@ void pack_stem(const float* wf, std::vector<uint16_t>& out) {
         }
 }
 
+// n / d for n < 2^31 as (umulhi(n, mul) >> shr): mul = ceil(2^(32+shr) / d), shr = ceil(log2 d) - 1
+// (exact: the error term n*e/2^(32+shr) stays below 1/d because n < 2^31 <= 2^(32+shr)/d).
+FastDiv make_fast_div(unsigned d) {
+    FastDiv f{0u, 0u};
+    if (d <= 1u) return f;
+    unsigned L = 0;
+    while ((1ull << L) < d) ++L;
+    f.shr = L - 1;
+    const unsigned long long num = 1ull << (32 + f.shr);
+    f.mul = (unsigned)((num + d - 1) / d);
+    return f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // launches
 // ---------------------------------------------------------------------------------------------
 // Tile-config ids of igemm_bf16_kernel (BC couts x BP pixels):
-//   4 waves, 2 LDS stages (LDS-DMA; +16 = register staging): 1 = 128x128, 2 = 64x128, 3 = 64x256, 5 = 128x64
-//   8 waves, 3 LDS stages, counted vmcnt (MFMA-bound layers): 6 = 256x128, 7 = 128x256, 8 = 128x128,
-//                                                             9 = 256x64, 10 = 64x256
-constexpr int kRegStageBit = 16;
+//   4 waves, 2 LDS stages:                1 = 128x128, 2 = 64x128, 3 = 64x256, 5 = 128x64
+//   8 waves, 3 LDS stages, counted vmcnt: 6 = 256x128, 7 = 128x256, 8 = 128x128
+//   + 32: chip-sized persistent grid (tiles streamed through the LDS ring) instead of one tile per workgroup
+constexpr int kPersistBit = 32;
+int g_num_cus = 0;
 
-template <int BC, int BP, int WC, int WP, int MODE>
-hipError_t launch_igemm_t(ConvArgs a, hipStream_t s) {
+template <int BC, int BP, int WC, int WP, int NSTAGE>
+hipError_t launch_igemm_t(ConvArgs a, bool persistent, hipStream_t s) {
     a.n_ctiles = a.Cout / BC;
     a.n_blocks = a.n_ctiles * ((a.M + BP - 1) / BP);
-    const int stages = (MODE == IGEMM_GLDS3) ? 3 : (a.nk > 1 ? 2 : 1);
-    const size_t lds = (size_t)stages * (BC + BP) * 128;
-    auto kern = igemm_bf16_kernel<BC, BP, WC, WP, MODE>;
+    a.div_ctiles = make_fast_div((unsigned)a.n_ctiles);
+    const size_t lds = (size_t)NSTAGE * (BC + BP) * 128;
+    auto kern = igemm_bf16_kernel<BC, BP, WC, WP, NSTAGE>;
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(a.n_blocks), dim3(WC * WP * 64), lds, s, a);
+    int grid = a.n_blocks;
+    if (persistent) {
+        if (g_num_cus == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+            g_num_cus = prop.multiProcessorCount;
+        }
+        // resident workgroups per CU (LDS / registers / wave slots).  No workgroup waits on another one,
+        // so an optimistic answer only queues the surplus workgroups; it cannot deadlock.
+        static int per_cu = 0;
+        if (per_cu == 0) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, WC * WP * 64, lds) != hipSuccess || n < 1) n = 1;
+            per_cu = n;
+        }
+        if (grid > g_num_cus * per_cu) grid = g_num_cus * per_cu;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WC * WP * 64), lds, s, a);
     return hipGetLastError();
 }
 
+// Tile choice.  For the 23 conv shapes of ResNet-50 at large batch the table holds the variant measured
+// fastest on an MI355X at batch 256 (scripts/layer_bench.py, profiles/r01_layer_bench.txt); anything else
+// falls back to a shape rule.
+struct TunedTile { int h, cin, cout, ks, stride, res, tile; };
+constexpr TunedTile kTuned[] = {
+    {56, 64, 64, 1, 1, 0, 34},    {56, 64, 64, 3, 1, 0, 2},     {56, 64, 256, 1, 1, 1, 39},   {56, 64, 256, 1, 1, 0, 38},
+    {56, 256, 64, 1, 1, 0, 2},    {56, 256, 128, 1, 1, 0, 40},  {56, 128, 128, 3, 2, 0, 33},  {28, 128, 512, 1, 1, 1, 40},
+    {56, 256, 512, 1, 2, 0, 38},  {28, 512, 128, 1, 1, 0, 2},   {28, 128, 128, 3, 1, 0, 33},  {28, 512, 256, 1, 1, 0, 38},
+    {28, 256, 256, 3, 2, 0, 1},   {14, 256, 1024, 1, 1, 1, 2},  {28, 512, 1024, 1, 2, 0, 1},  {14, 1024, 256, 1, 1, 0, 1},
+    {14, 256, 256, 3, 1, 0, 1},   {14, 1024, 512, 1, 1, 0, 33}, {14, 512, 512, 3, 2, 0, 33},  {7, 512, 2048, 1, 1, 1, 33},
+    {14, 1024, 2048, 1, 2, 0, 33}, {7, 2048, 512, 1, 1, 0, 1},  {7, 512, 512, 3, 1, 0, 33},
+};
+
 int auto_tile(const ConvArgs& a) {
+    if (a.N >= 96 && a.H == a.W)
+        for (const TunedTile& t : kTuned)
+            if (t.h == a.H && t.cin == a.Cin && t.cout == a.Cout && t.ks == a.ks && t.stride == a.stride &&
+                t.res == (a.res != nullptr))
+                return t.tile;
     if (a.Cout % 128) return 2;
-    if (a.res != nullptr) return 5;
+    if (a.M <= 128 * 128) return 5;       // few pixel tiles: smaller tiles fill more CUs
     return 1;
 }
 
 hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s) {
     if (tile == 0) tile = auto_tile(a);
-    const bool reg = (tile & kRegStageBit) != 0;
-    const int id = tile & (kRegStageBit - 1);
-#define R50_DISPATCH2(BC, BP, WC, WP)                                                     \
-    return reg ? launch_igemm_t<BC, BP, WC, WP, IGEMM_REG2>(a, s) : launch_igemm_t<BC, BP, WC, WP, IGEMM_GLDS2>(a, s)
-#define R50_DISPATCH3(BC, BP, WC, WP)                                                     \
-    if (reg) return hipErrorInvalidValue;                                                 \
-    return launch_igemm_t<BC, BP, WC, WP, IGEMM_GLDS3>(a, s)
-    switch (id) {
-        case 1: if (a.Cout % 128) return hipErrorInvalidValue; R50_DISPATCH2(128, 128, 2, 2);
-        case 2: R50_DISPATCH2(64, 128, 1, 4);
-        case 3: R50_DISPATCH2(64, 256, 1, 4);
-        case 5: if (a.Cout % 128) return hipErrorInvalidValue; R50_DISPATCH2(128, 64, 2, 2);
-        case 6: if (a.Cout % 256) return hipErrorInvalidValue; R50_DISPATCH3(256, 128, 4, 2);
-        case 7: if (a.Cout % 128) return hipErrorInvalidValue; R50_DISPATCH3(128, 256, 2, 4);
-        case 8: if (a.Cout % 128) return hipErrorInvalidValue; R50_DISPATCH3(128, 128, 2, 4);
-        case 9: if (a.Cout % 256) return hipErrorInvalidValue; R50_DISPATCH3(256, 64, 4, 2);
-        case 10: R50_DISPATCH3(64, 256, 1, 8);
+    const bool pers = (tile & kPersistBit) != 0;
+    switch (tile & (kPersistBit - 1)) {
+        case 1: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 128, 2, 2, 2>(a, pers, s);
+        case 2: return launch_igemm_t<64, 128, 1, 4, 2>(a, pers, s);
+        case 3: return launch_igemm_t<64, 256, 1, 4, 2>(a, pers, s);
+        case 5: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 64, 2, 2, 2>(a, pers, s);
+        case 6: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 128, 4, 2, 3>(a, pers, s);
+        case 7: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 256, 2, 4, 3>(a, pers, s);
+        case 8: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 128, 2, 4, 3>(a, pers, s);
         default: return hipErrorInvalidValue;
     }
-#undef R50_DISPATCH2
-#undef R50_DISPATCH3
 }
 
 int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, const void* wt, const float* bias,
-                   const void* res, void* y, int cout, int ks, int stride, int pad, int relu, const void* zero) {
-    if (!x || !wt || !bias || !y || !zero) return R50_ERR_INVALID;
+                   const void* res, void* y, int cout, int ks, int stride, int pad, int relu) {
+    if (!x || !wt || !bias || !y) return R50_ERR_INVALID;
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cin % 64 || cout <= 0 || cout % 64) return R50_ERR_INVALID;
     if (!(ks == 1 || ks == 3) || stride < 1 || pad < 0 || 2 * pad > ks - 1) return R50_ERR_INVALID;
     a.x = (const __bf16*)x; a.w = (const __bf16*)wt; a.bias = bias; a.res = (const __bf16*)res; a.y = (__bf16*)y;
-    a.zero = zero;
     a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;
     a.Ho = (h + 2 * pad - ks) / stride + 1;
     a.Wo = (w + 2 * pad - ks) / stride + 1;
@@ -232,6 +270,10 @@ int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, con
     if (x_bytes + a.x_back >= (1ll << 31) || (long long)cout * a.Ktot * 2 >= (1ll << 31)) return R50_ERR_INVALID;
     a.x_records = (unsigned)(x_bytes + a.x_back);
     a.w_bytes = (unsigned)((long long)cout * a.Ktot * 2);
+    a.y_bytes = (unsigned)(M * cout * 2);
+    a.div_howo = make_fast_div((unsigned)a.HoWo);
+    a.div_wo = make_fast_div((unsigned)a.Wo);
+    a.div_ctiles = FastDiv{0u, 0u};
     return R50_OK;
 }
 
@@ -256,7 +298,7 @@ void prof_end(r50_handle* h, hipStream_t s, EvRec& r) {
 int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, int ww, const __bf16* res,
              __bf16* y, int relu, hipStream_t s, int* ho, int* wo) {
     ConvArgs a;
-    int rc = fill_conv_args(a, x, n, hh, ww, L.cin, L.w, L.bias, res, y, L.cout, L.ks, L.stride, L.pad, relu, h->zero);
+    int rc = fill_conv_args(a, x, n, hh, ww, L.cin, L.w, L.bias, res, y, L.cout, L.ks, L.stride, L.pad, relu);
     if (rc) return fail(h, rc, "conv args invalid for " + L.conv_key);
     EvRec r{};
     const double flops = 2.0 * a.M * (double)a.Cout * a.Ktot;
@@ -379,23 +421,9 @@ void free_all(r50_handle* h) {
     if (h->stem_w) (void)hipFree(h->stem_w);
     if (h->stem_xp) (void)hipFree(h->stem_xp);
     for (auto& b : h->buf) { if (b) (void)hipFree(b); b = nullptr; }
-    if (h->zero) (void)hipFree(h->zero);
     for (auto& r : h->ev_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& e : h->ev_free) (void)hipEventDestroy(e);
     h->ev_pending.clear(); h->ev_free.clear();
-}
-
-// process-wide zero page for the op-level entry points
-void* g_zero_page[16] = {nullptr};
-int get_zero_page(void** out) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return R50_ERR_HIP;
-    if (!g_zero_page[dev]) {
-        if (hipMalloc(&g_zero_page[dev], 256) != hipSuccess) return R50_ERR_NOMEM;
-        if (hipMemset(g_zero_page[dev], 0, 256) != hipSuccess) return R50_ERR_HIP;
-    }
-    *out = g_zero_page[dev];
-    return R50_OK;
 }
 
 }  // namespace
@@ -430,7 +458,6 @@ int r50_create(r50_handle** out, int device_id, int precision, int max_batch) {
     for (int i = 0; i < 5 && ok; ++i) ok = hipMalloc((void**)&h->buf[i], h->buf_bytes) == hipSuccess;
     ok = ok && hipMalloc((void**)&h->stem_xp, (size_t)max_batch * STEM_HP * STEM_WP * 8) == hipSuccess;
     ok = ok && hipMalloc((void**)&h->stem_w, STEM_W_BYTES) == hipSuccess;
-    ok = ok && hipMalloc(&h->zero, 256) == hipSuccess && hipMemset(h->zero, 0, 256) == hipSuccess;
     if (!ok) {
         free_all(h);
         delete h;
@@ -608,11 +635,8 @@ int r50_get_packed(r50_handle* h, const char* conv_key, int what, void* dst_host
 // ---- op-level entry points -------------------------------------------------------------------
 int r50_op_conv2d(const void* x, int n, int h, int w, int cin, const void* wt, const float* bias, const void* res,
                   void* y, int cout, int ksize, int stride, int pad, int relu, int tile, void* stream) {
-    void* zero = nullptr;
-    int rc = get_zero_page(&zero);
-    if (rc) return fail(nullptr, rc, "r50_op_conv2d: zero page allocation failed");
     ConvArgs a;
-    rc = fill_conv_args(a, x, n, h, w, cin, wt, bias, res, y, cout, ksize, stride, pad, relu, zero);
+    int rc = fill_conv_args(a, x, n, h, w, cin, wt, bias, res, y, cout, ksize, stride, pad, relu);
     if (rc) return fail(nullptr, rc, "r50_op_conv2d: invalid arguments");
     hipError_t e = launch_igemm(a, tile, (hipStream_t)stream);
     if (e != hipSuccess) return fail(nullptr, R50_ERR_HIP, std::string("r50_op_conv2d: ") + hipGetErrorString(e));

@@ -12,18 +12,16 @@ import torch
 
 from . import _lib
 
-# tile-config ids of the implicit-GEMM kernel (DESIGN.md "Kernels"); +REG_STAGE = register staging
+# tile-config ids of the implicit-GEMM kernel (BC couts x BP pixels; DESIGN.md "Kernels")
 TILE_AUTO = 0
-TILE_128x128 = 1
+TILE_128x128 = 1         # 4 waves, 2 LDS stages
 TILE_64x128 = 2
 TILE_64x256 = 3
 TILE_128x64 = 5
 TILE_256x128_P3 = 6      # 8 waves, 3 LDS stages, counted vmcnt
 TILE_128x256_P3 = 7
 TILE_128x128_P3 = 8
-TILE_256x64_P3 = 9
-TILE_64x256_P3 = 10
-REG_STAGE = 16           # + REG_STAGE on the 2-stage tiles: register staging instead of LDS-DMA
+PERSISTENT = 32          # + PERSISTENT: chip-sized grid, tiles streamed through the LDS ring
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -36,8 +34,11 @@ def _need(t: torch.Tensor, dtype, name: str) -> None:
 
 
 def conv2d_bf16(x: torch.Tensor, w_ohwi: torch.Tensor, bias: torch.Tensor, stride: int = 1, pad: int = 0,
-                relu: bool = True, residual: Optional[torch.Tensor] = None, tile: int = TILE_AUTO) -> torch.Tensor:
-    """x (N,H,W,Cin) bf16, w_ohwi (Cout,k,k,Cin) bf16, bias (Cout) fp32 -> (N,Ho,Wo,Cout) bf16."""
+                relu: bool = True, residual: Optional[torch.Tensor] = None, tile: int = TILE_AUTO,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (N,H,W,Cin) bf16, w_ohwi (Cout,k,k,Cin) bf16, bias (Cout) fp32 -> (N,Ho,Wo,Cout) bf16.
+    ``out``: optional flat bf16 buffer with at least N*Ho*Wo*Cout elements (tests use it to put a
+    guard band behind the result)."""
     _need(x, torch.bfloat16, "x"); _need(w_ohwi, torch.bfloat16, "w"); _need(bias, torch.float32, "bias")
     n, h, w, cin = x.shape
     cout, k, k2, cin2 = w_ohwi.shape
@@ -45,7 +46,13 @@ def conv2d_bf16(x: torch.Tensor, w_ohwi: torch.Tensor, bias: torch.Tensor, strid
         raise ValueError("conv2d_bf16: inconsistent shapes")
     ho = (h + 2 * pad - k) // stride + 1
     wo = (w + 2 * pad - k) // stride + 1
-    y = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=x.device)
+    if out is not None:
+        _need(out, torch.bfloat16, "out")
+        if out.numel() < n * ho * wo * cout:
+            raise ValueError("conv2d_bf16: out buffer too small")
+        y = out.view(-1)[: n * ho * wo * cout].view(n, ho, wo, cout)
+    else:
+        y = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=x.device)
     if residual is not None:
         _need(residual, torch.bfloat16, "residual")
         if residual.shape != y.shape:
