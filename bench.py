@@ -156,9 +156,19 @@ def main() -> None:
         bb.set_option("profile", 0)
         ig = prof["igemm"]
         achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        traffic = None          # HBM bytes per igemm launch from rocprofv3 PMC passes (scripts/pmc_bench.sh), committed
+        tpath = ROOT / "profiles" / "r01_pmc_hbm_traffic.json"
+        if tpath.exists():
+            try:
+                traffic = json.loads(tpath.read_text())["igemm"]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
         roofline = {"bound": "mfma", "kernel": "igemm_bf16_kernel (52 conv launches/step)", "achieved": achieved,
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                    "traffic": None,
+                    "traffic": traffic,
+                    "traffic_note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch, batch 256, from "
+                                    "profiles/r01_pmc_hbm_traffic.json; algorithmic layer-wise bytes/launch = "
+                                    "layerwise_GBps x avg_launch_us",
                     "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
                     "flops_per_launch": ig["flops"] / max(1, ig["launches"]),
                     "layerwise_GBps": ig["bytes"] / (ig["ms"] * 1e-3) / 1e9 if ig["ms"] > 0 else 0.0}

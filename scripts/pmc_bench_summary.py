@@ -1,0 +1,25 @@
+"""Aggregate gpurun_out/pmcb_{FETCH_SIZE,WRITE_SIZE} into per-kernel-class HBM traffic per launch.
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of the bytes of wide coalesced
+reads -> doubled; WRITE_SIZE is exact for 16-B/lane stores.  Both counters are in KiB."""
+import csv, glob, json, collections, sys
+out = {}
+for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(f"gpurun_out/pmcb_{cname}/**/*counter_collection.csv", recursive=True)
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != cname: continue
+            k = r["Kernel_Name"]
+            cls = "igemm" if "igemm" in k else "conv1" if "stem_conv" in k else "stem_pack" if "stem_pack" in k else \
+                  "maxpool" if "maxpool" in k else "avgpool" if "avgpool" in k else None
+            if cls is None: continue
+            a = agg[cls]; a[0] += 1; a[1] += float(r["Counter_Value"]) * 1024.0
+    for cls, (n, b) in agg.items():
+        out.setdefault(cls, {})[cname] = {"launches": n, "bytes_per_launch_raw": b / n}
+res = {}
+for cls, d in out.items():
+    f = d.get("FETCH_SIZE", {}).get("bytes_per_launch_raw", 0.0)
+    w = d.get("WRITE_SIZE", {}).get("bytes_per_launch_raw", 0.0)
+    res[cls] = {"launches_counted": d.get("FETCH_SIZE", {}).get("launches", 0), "fetch_bytes_per_launch_raw": f,
+                "fetch_bytes_per_launch_x2": 2 * f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": 2 * f + w}
+json.dump(res, sys.stdout, indent=1)
