@@ -83,6 +83,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="frames per GPU per step (headline config: 256)")
     ap.add_argument("--micro-batch", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=0, help="internal streams the batch is split over (0 = library default)")
+    ap.add_argument("--precision", choices=["bf16", "fp32x"], default="bf16",
+                    help="bf16 = headline path; fp32x = fp32-class accuracy mode (bf16 head/tail pairs, 3 products per conv)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -114,7 +117,9 @@ def main() -> None:
         dist.barrier()
 
     sd = synthetic_state_dict(0)
-    bb = ResNet50Backbone(state_dict=sd, max_batch=args.batch, micro_batch=args.micro_batch).to(dev).eval()
+    bb = ResNet50Backbone(state_dict=sd, max_batch=args.batch, micro_batch=args.micro_batch, precision=args.precision).to(dev).eval()
+    if args.streams:
+        bb.set_option("streams", args.streams)
     x = synthetic_frames(args.batch, seed=1234 + rank).to(dev)          # random data, resident in HBM
     feats = torch.empty((args.batch, 2048), dtype=torch.float32, device=dev)
     gathered = [torch.empty_like(feats) for _ in range(world)] if (dist is not None and rank == 0) else None
@@ -191,7 +196,7 @@ def main() -> None:
             "metric": "H36M frames/sec ResNet-50 feature extraction",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (fp32-class)", "data": "synthetic",
             "config": {"workload": f"ResNet-50[:-1] bf16 forward, batch {args.batch} x 224x224x3 fp32 NCHW frames per GPU "
                                    f"(BASELINE configs[1]), seeded synthetic weights, (N,2048) fp32 features"
                                    + (", RCCL gather to rank 0" if world > 1 else ""),

@@ -22,7 +22,9 @@ import torch
 from . import _lib
 from .weights import FEATURE_DIM, iter_named_tensors, load_state_dict_from_path, synthetic_state_dict, validate_state_dict
 
-PREC_BF16 = 1
+PREC_BF16 = 1     # bf16 operands, fp32 accumulation: the fast path (the reference's CUDA autocast dtype)
+PREC_FP32X = 2    # fp32-class accuracy on the bf16 matrix cores (bf16 head/tail pairs, 3 products per conv)
+_PRECISIONS = {"bf16": PREC_BF16, "fp32x": PREC_FP32X, PREC_BF16: PREC_BF16, PREC_FP32X: PREC_FP32X}
 
 
 class ResNet50Backbone:
@@ -33,13 +35,16 @@ class ResNet50Backbone:
     """
 
     def __init__(self, state_dict: Optional[Dict[str, torch.Tensor]] = None, weights_path: Optional[str] = None,
-                 seed: int = 0, max_batch: int = 256, micro_batch: int = 0):
+                 seed: int = 0, max_batch: int = 256, micro_batch: int = 0, precision="bf16"):
         if state_dict is None:
             state_dict = load_state_dict_from_path(weights_path) if weights_path else synthetic_state_dict(seed)
         validate_state_dict(state_dict)
         self._sd = state_dict
         self._max_batch = int(max_batch)
         self._micro_batch = int(micro_batch)
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be 'bf16' or 'fp32x', got {precision!r}")
+        self._precision = _PRECISIONS[precision]
         self._handle: Optional[int] = None
         self._device: Optional[torch.device] = None
         self.training = False
@@ -57,7 +62,7 @@ class ResNet50Backbone:
         self._release()
         lib = _lib.load_library()
         h = C.c_void_p()
-        _lib.check(lib.r50_create(C.byref(h), index, PREC_BF16, self._max_batch), None, "r50_create")
+        _lib.check(lib.r50_create(C.byref(h), index, self._precision, self._max_batch), None, "r50_create")
         self._handle = h.value
         self._device = device
         named = list(iter_named_tensors(self._sd))
@@ -118,18 +123,23 @@ class ResNet50Backbone:
         return out
 
     def layer(self, x: torch.Tensor, name: str) -> torch.Tensor:
-        """Debug hook: named intermediate activation as a bf16 NHWC tensor (per-layer parity tests)."""
+        """Debug hook: named intermediate activation, NHWC (per-layer parity tests).  bf16 tensor in bf16
+        mode; in fp32x mode the (head, tail) pair is recombined into an fp32 tensor."""
         x = self._check_input(x)
         n = x.shape[0]
         lib = _lib.load_library()
-        cap = n * 112 * 112 * 64
+        cap = n * 112 * 112 * 64 * (2 if self._precision == PREC_FP32X else 1)
         buf = torch.empty(cap, dtype=torch.bfloat16, device=self._device)
         dims = (C.c_int64 * 4)()
         stream = torch.cuda.current_stream(self._device).cuda_stream
         _lib.check(lib.r50_forward_layer(self._handle, x.data_ptr(), n, name.encode(), buf.data_ptr(), cap * 2, dims, stream),
                    self._handle, "r50_forward_layer")
         d = [int(v) for v in dims]
-        return buf[: d[0] * d[1] * d[2] * d[3]].view(*d)
+        t = buf[: d[0] * d[1] * d[2] * d[3]].view(*d)
+        if self._precision == PREC_FP32X:
+            c = d[3] // 2
+            return t[..., :c].float() + t[..., c:].float()
+        return t
 
     def packed_params(self, conv_key: str):
         """Debug hook: (folded bf16 weights in (cout,k,k,cin) order, folded fp32 bias) as the device holds them."""

@@ -85,8 +85,11 @@ struct ConvArgs {
     int x_back;           // bytes the X descriptor base sits before x: (pad*W + pad)*Cin*2
     unsigned x_records;   // X descriptor size: activation bytes + x_back (< 2^31)
     unsigned w_bytes;     // W descriptor size
-    unsigned y_bytes;     // Y / residual descriptor size: M*Cout*2
+    unsigned y_bytes;     // Y / residual descriptor size: M*y_cstride*2
     FastDiv div_howo, div_wo, div_ctiles;
+    int x_cstride;        // channels per pixel of the X tensor (Cin; 2*Cin in split mode: [hi | lo])
+    int x_wrap;           // K chunk index at which the X chunk index wraps to 0 again (split: 2*Cin/64; else huge)
+    int y_cstride;        // channels per pixel of Y / residual (Cout; 2*Cout in split mode)
 };
 
 __device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv d) {
@@ -109,7 +112,7 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned v) {   // max(x, 0) on 
 
 constexpr unsigned kOobOffset = 0x80000000u;
 
-template <int BC, int BP, int WC, int WP, int NSTAGE>
+template <int BC, int BP, int WC, int WP, int NSTAGE, bool SPLIT = false>
 __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body only in the device pass: the host pass needs just the launch stub
                                       // (the LDS-DMA buffer builtin has no host-side lowering)
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
                 const int ho = (int)fast_div((unsigned)r, a.div_wo);
                 const int wo = r - ho * a.Wo;
                 const int hc = ho * a.stride, wc = wo * a.stride;          // reference tap (pad,pad): always inside
-                voff = (unsigned)(((n * a.H + hc) * a.W + wc) * a.Cin + lchunk * 8) * 2u;
+                voff = (unsigned)(((n * a.H + hc) * a.W + wc) * a.x_cstride + lchunk * 8) * 2u;
                 if (a.ks == 1) {
                     mask = 1u;
                 } else {                                                    // ks == 3: bit (dh*3 + dw)
@@ -187,11 +190,13 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
         }
     };
     int i_tile = first, i_k = 0, i_tap = 0, i_cc = 0, i_dw = 0, i_wofs = 0, i_tapofs = 0, i_buf = 0;
-    const int row_adv = (a.W - a.ks) * a.Cin * 2;  // extra displacement when dw wraps to the next kernel row
+    const int row_adv = (a.W - a.ks) * a.x_cstride * 2;  // extra displacement when dw wraps to the next kernel row
     decode_tile(i_tile);
     auto stage_issue = [&]() {
         char* sbase = smem + i_buf * STAGE_BYTES;
-        const int xofs = i_tapofs + i_cc * 128;
+        // split mode: K per tap is [x_hi | x_lo | x_hi] against [w_hi | w_hi | w_lo]; the third block re-reads x_hi
+        const int xcc = (i_cc >= a.x_wrap) ? i_cc - a.x_wrap : i_cc;
+        const int xofs = i_tapofs + xcc * 128;
 #pragma unroll
         for (int i = 0; i < WROWS; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (LDS_AS void*)(sbase + i * PASS_BYTES + wave * 1024), 16,
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
         if (++i_cc == a.cin_chunks) {
             i_cc = 0;
             ++i_tap;
-            i_tapofs += a.Cin * 2;
+            i_tapofs += a.x_cstride * 2;
             if (++i_dw == a.ks) { i_dw = 0; i_tapofs += row_adv; }
         }
         if (++i_k == a.nk) {                       // next tile of this workgroup's stream
@@ -228,12 +233,12 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
     const int pix_lane = wave_p * NR * 16 + fr;
     int c_tile = first, c_k = 0, c_buf = 0;
     unsigned y_voff = 0u;                          // byte offset of (tile pixel0 + lane pixel, tile cout0 + lane cout)
-    const unsigned y_rowstep = (unsigned)(16 * a.Cout * 2);   // 16 pixels further (next pixel block of the wave)
+    const unsigned y_rowstep = (unsigned)(16 * a.y_cstride * 2);   // 16 pixels further (next pixel block of the wave)
 
     auto tile_begin = [&]() {                      // accumulators start at the bias; residual fetched early
         const int pt = (int)fast_div((unsigned)c_tile, a.div_ctiles);
         const int c0 = (c_tile - pt * a.n_ctiles) * BC, p0 = pt * BP;
-        y_voff = (unsigned)((p0 + pix_lane) * a.Cout + c0 + cout_lane) * 2u;
+        y_voff = (unsigned)((p0 + pix_lane) * a.y_cstride + c0 + cout_lane) * 2u;
 #pragma unroll
         for (int t = 0; t < MR / 2; ++t) {
             const f32x4 b_lo = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t);
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
             for (int j = 0; j < NR; ++j) {
                 acc[2 * t][j] = b_lo;
                 acc[2 * t + 1][j] = b_hi;
-                if (has_res)     // row displacement in voffset: soffset is not part of the range check
+                if (!SPLIT && has_res)     // row displacement in voffset: soffset is not part of the range check
                     res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, 0);
             }
         }
@@ -274,20 +279,48 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 f32x4 lo = acc[2 * t][j], hi = acc[2 * t + 1][j];
-                if (has_res) {
-                    const u32x4 r = res_reg[t][j];
-                    lo[0] += bf16_bits_to_f32(r[0] & 0xffffu); lo[1] += __uint_as_float(r[0] & 0xffff0000u);
-                    lo[2] += bf16_bits_to_f32(r[1] & 0xffffu); lo[3] += __uint_as_float(r[1] & 0xffff0000u);
-                    hi[0] += bf16_bits_to_f32(r[2] & 0xffffu); hi[1] += __uint_as_float(r[2] & 0xffff0000u);
-                    hi[2] += bf16_bits_to_f32(r[3] & 0xffffu); hi[3] += __uint_as_float(r[3] & 0xffff0000u);
-                }
-                u32x4 out = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                                    pack_bf16x2(hi[2], hi[3])};
-                if (a.relu) {
+                const unsigned voff = y_voff + j * y_rowstep + 64 * t;
+                if constexpr (!SPLIT) {
+                    if (has_res) {
+                        const u32x4 r = res_reg[t][j];
+                        lo[0] += bf16_bits_to_f32(r[0] & 0xffffu); lo[1] += __uint_as_float(r[0] & 0xffff0000u);
+                        lo[2] += bf16_bits_to_f32(r[1] & 0xffffu); lo[3] += __uint_as_float(r[1] & 0xffff0000u);
+                        hi[0] += bf16_bits_to_f32(r[2] & 0xffffu); hi[1] += __uint_as_float(r[2] & 0xffff0000u);
+                        hi[2] += bf16_bits_to_f32(r[3] & 0xffffu); hi[3] += __uint_as_float(r[3] & 0xffff0000u);
+                    }
+                    u32x4 out = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                                        pack_bf16x2(hi[2], hi[3])};
+                    if (a.relu) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) out[e] = relu_bf16x2(out[e]);
+                        for (int e = 0; e < 4; ++e) out[e] = relu_bf16x2(out[e]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, 0);
+                } else {
+                    // split mode: values travel as bf16 pairs (head, tail) with head + tail ~ fp32 (16 mantissa bits)
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (has_res) {
+                        const u32x4 rh = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, 0, 0);
+                        const u32x4 rl = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, a.Cout * 2, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += bf16_bits_to_f32(rh[e] & 0xffffu) + bf16_bits_to_f32(rl[e] & 0xffffu);
+                            v[2 * e + 1] += __uint_as_float(rh[e] & 0xffff0000u) + __uint_as_float(rl[e] & 0xffff0000u);
+                        }
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    u32x4 head, tail;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        head[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                        tail[e] = pack_bf16x2(v[2 * e] - bf16_bits_to_f32(head[e] & 0xffffu),
+                                              v[2 * e + 1] - __uint_as_float(head[e] & 0xffff0000u));
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(head, rsrc_y, voff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(tail, rsrc_y, voff, a.Cout * 2, 0);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, y_voff + j * y_rowstep + 64 * t, 0, 0);
             }
         }
     };
@@ -488,6 +521,194 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const __bf16* __restrict__
         for (int e = 0; e < 4; ++e) {
             s[2 * e] += bf16_bits_to_f32(v[e] & 0xffffu);
             s[2 * e + 1] += bf16_bits_to_f32(v[e] >> 16);
+        }
+    }
+    float* o = y + (size_t)n * C + g * 8;
+    *reinterpret_cast<f32x4*>(o) = (f32x4){s[0] * inv_hw, s[1] * inv_hw, s[2] * inv_hw, s[3] * inv_hw};
+    *reinterpret_cast<f32x4*>(o + 4) = (f32x4){s[4] * inv_hw, s[5] * inv_hw, s[6] * inv_hw, s[7] * inv_hw};
+}
+
+// ================================================================================================
+// Split-precision ("fp32x") variants of the non-GEMM kernels.  In this mode every activation travels
+// as a pair of bf16 tensors (head, tail) with head + tail ~ the fp32 value (16 mantissa bits), stored
+// channel-concatenated per pixel: [head(C) | tail(C)].  Convolutions run three bf16 MFMA products
+// (x_head*w_head + x_tail*w_head + x_head*w_tail) with fp32 accumulation -- fp32-class accuracy on the
+// bf16 matrix cores, about 3x the bf16 work (gfx950 has no TF32-like mode and its fp32 MFMA runs at
+// 1/16 of the bf16 rate).
+// ================================================================================================
+__device__ __forceinline__ void split_bf16(float v, unsigned& head16, unsigned& tail16) {
+    const unsigned h = pack_bf16x2(v, 0.f) & 0xffffu;
+    head16 = h;
+    tail16 = pack_bf16x2(v - bf16_bits_to_f32(h), 0.f) & 0xffffu;
+}
+
+__global__ __launch_bounds__(256) void stem_pack_split_kernel(const float* __restrict__ x, u32x2* __restrict__ xp_head,
+                                                              u32x2* __restrict__ xp_tail, int n_img) {
+    const long long total = (long long)n_img * STEM_HP * STEM_WP;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int wp = (int)(idx % STEM_WP);
+        const long long t = idx / STEM_WP;
+        const int hp = (int)(t % STEM_HP);
+        const int n = (int)(t / STEM_HP);
+        const int hi = hp - 3, wi = wp - 4;
+        u32x2 oh = (u32x2){0u, 0u}, ot = (u32x2){0u, 0u};
+        if ((unsigned)hi < 224u && (unsigned)wi < 224u) {
+            const float* p = x + ((size_t)n * 3 * 224 + hi) * 224 + wi;
+            unsigned h0, t0, h1, t1, h2, t2;
+            split_bf16(p[0], h0, t0);
+            split_bf16(p[224 * 224], h1, t1);
+            split_bf16(p[2 * 224 * 224], h2, t2);
+            oh[0] = h0 | (h1 << 16); oh[1] = h2;
+            ot[0] = t0 | (t1 << 16); ot[1] = t2;
+        }
+        xp_head[idx] = oh;
+        xp_tail[idx] = ot;
+    }
+}
+
+constexpr int STEM_SPLIT_LDS_BYTES = 2 * STEM_W_BYTES + 2 * STEM_IN_ROWS * STEM_ROW_BYTES;
+
+// y: (N,112,112,128) = [head(64) | tail(64)] per pixel
+__global__ __launch_bounds__(256) void stem_conv_split_kernel(const char* __restrict__ xp_head, const char* __restrict__ xp_tail,
+                                                              const char* __restrict__ w_head, const char* __restrict__ w_tail,
+                                                              const float* __restrict__ bias, __bf16* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int IN_BYTES = STEM_IN_ROWS * STEM_ROW_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x / (112 / STEM_ROWS_PER_WG);
+    const int ho0 = (blockIdx.x % (112 / STEM_ROWS_PER_WG)) * STEM_ROWS_PER_WG;
+
+    for (int c = tid; c < STEM_W_BYTES / 16; c += 256) {
+        *reinterpret_cast<u32x4*>(smem + c * 16) = *reinterpret_cast<const u32x4*>(w_head + c * 16);
+        *reinterpret_cast<u32x4*>(smem + STEM_W_BYTES + c * 16) = *reinterpret_cast<const u32x4*>(w_tail + c * 16);
+    }
+    const size_t src_off = ((size_t)n * STEM_HP + 2 * ho0) * STEM_ROW_BYTES;
+    for (int c = tid; c < IN_BYTES / 16; c += 256) {
+        *reinterpret_cast<u32x4*>(smem + 2 * STEM_W_BYTES + c * 16) = *reinterpret_cast<const u32x4*>(xp_head + src_off + c * 16);
+        *reinterpret_cast<u32x4*>(smem + 2 * STEM_W_BYTES + IN_BYTES + c * 16) =
+            *reinterpret_cast<const u32x4*>(xp_tail + src_off + c * 16);
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4 acc[4][7];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int w_frag = fr * 64 + fq * 16;
+    const int x_frag = (2 * wave) * STEM_ROW_BYTES + fr * 16 + fq * 16;
+#pragma unroll
+    for (int combo = 0; combo < 3; ++combo) {            // (x_head,w_head) (x_tail,w_head) (x_head,w_tail)
+        const char* wbase = smem + (combo == 2 ? STEM_W_BYTES : 0);
+        const char* xbase = smem + 2 * STEM_W_BYTES + (combo == 1 ? IN_BYTES : 0);
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            bf16x8 wf[4], xf[7];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(wbase + kh * 4096 + m * 1024 + w_frag);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xbase + x_frag + kh * STEM_ROW_BYTES + j * 256);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[j], acc[m][j], 0, 0, 0);
+        }
+    }
+    const int ho = ho0 + wave;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int cout = 32 * t + 8 * fq;
+        const f32x4 b_lo = *reinterpret_cast<const f32x4*>(bias + cout);
+        const f32x4 b_hi = *reinterpret_cast<const f32x4*>(bias + cout + 4);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int wo = 16 * j + fr;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = fmaxf(acc[2 * t][j][e] + b_lo[e], 0.f);
+                v[4 + e] = fmaxf(acc[2 * t + 1][j][e] + b_hi[e], 0.f);
+            }
+            u32x4 head, tail;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                head[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                tail[e] = pack_bf16x2(v[2 * e] - bf16_bits_to_f32(head[e] & 0xffffu), v[2 * e + 1] - __uint_as_float(head[e] & 0xffff0000u));
+            }
+            __bf16* o = y + (((size_t)n * 112 + ho) * 112 + wo) * 128 + cout;
+            *reinterpret_cast<u32x4*>(o) = head;
+            *reinterpret_cast<u32x4*>(o + 64) = tail;
+        }
+    }
+}
+
+// MaxPool2d(3,2,1) on [head(C) | tail(C)] pixels: compares head + tail, writes the re-split maximum.
+__global__ __launch_bounds__(256) void maxpool3x3s2_split_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, int N,
+                                                                 int H, int W, int C, int Ho, int Wo) {
+    const int cg = C >> 3;
+    const long long total = (long long)N * Ho * Wo * cg;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % cg);
+        long long t = idx / cg;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -__builtin_huge_valf();
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int hi = 2 * ho - 1 + dh;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int wi = 2 * wo - 1 + dw;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const __bf16* p = x + (((size_t)n * H + hi) * W + wi) * (2 * C) + g * 8;
+                const u32x4 vh = *reinterpret_cast<const u32x4*>(p);
+                const u32x4 vt = *reinterpret_cast<const u32x4*>(p + C);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    m[2 * e] = fmaxf(m[2 * e], bf16_bits_to_f32(vh[e] & 0xffffu) + bf16_bits_to_f32(vt[e] & 0xffffu));
+                    m[2 * e + 1] = fmaxf(m[2 * e + 1], __uint_as_float(vh[e] & 0xffff0000u) + __uint_as_float(vt[e] & 0xffff0000u));
+                }
+            }
+        }
+        u32x4 head, tail;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            head[e] = pack_bf16x2(m[2 * e], m[2 * e + 1]);
+            tail[e] = pack_bf16x2(m[2 * e] - bf16_bits_to_f32(head[e] & 0xffffu), m[2 * e + 1] - __uint_as_float(head[e] & 0xffff0000u));
+        }
+        __bf16* o = y + (idx / cg) * (2 * C) + g * 8;
+        *reinterpret_cast<u32x4*>(o) = head;
+        *reinterpret_cast<u32x4*>(o + C) = tail;
+    }
+}
+
+// Global average pool on [head(C) | tail(C)] pixels -> (N, C) fp32.
+__global__ __launch_bounds__(256) void avgpool_split_kernel(const __bf16* __restrict__ x, float* __restrict__ y, int N, int HW,
+                                                            int C, float inv_hw) {
+    const int cg = C >> 3;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * cg) return;
+    const int g = idx % cg, n = idx / cg;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    const __bf16* p = x + (size_t)n * HW * (2 * C) + g * 8;
+    for (int r = 0; r < HW; ++r) {
+        const u32x4 vh = *reinterpret_cast<const u32x4*>(p + (size_t)r * 2 * C);
+        const u32x4 vt = *reinterpret_cast<const u32x4*>(p + (size_t)r * 2 * C + C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s[2 * e] += bf16_bits_to_f32(vh[e] & 0xffffu) + bf16_bits_to_f32(vt[e] & 0xffffu);
+            s[2 * e + 1] += __uint_as_float(vh[e] & 0xffff0000u) + __uint_as_float(vt[e] & 0xffff0000u);
         }
     }
     float* o = y + (size_t)n * C + g * 8;

@@ -46,6 +46,9 @@ struct r50_handle {
     int micro_batch = 0;
     int profile = 0;
     int tile_override = 0;
+    int n_streams = 2;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool loaded = false;
     std::string err;
     std::vector<ConvLayer> convs;       // execution order, convs[0] = stem
@@ -133,20 +136,45 @@ void pack_ohwi_bf16(const float* wf, int cout, int cin, int ks, std::vector<uint
                 out[((size_t)o * ks * ks + t) * cin + c] = f32_to_bf16_rne(wf[((size_t)o * cin + c) * ks * ks + t]);
 }
 
+inline float bf16_to_f32(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// split mode: (cout, cin, k, k) fp32 -> (cout, k, k, [w_head(cin) | w_head(cin) | w_tail(cin)]) bf16,
+// w_head = bf16(w), w_tail = bf16(w - w_head); pairs with X = [x_head | x_tail | x_head]
+void pack_ohwi_split(const float* wf, int cout, int cin, int ks, std::vector<uint16_t>& out) {
+    out.resize((size_t)cout * ks * ks * 3 * cin);
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < ks * ks; ++t) {
+                const float w = wf[((size_t)o * cin + c) * ks * ks + t];
+                const uint16_t hd = f32_to_bf16_rne(w);
+                const uint16_t tl = f32_to_bf16_rne(w - bf16_to_f32(hd));
+                uint16_t* row = &out[((size_t)o * ks * ks + t) * 3 * cin];
+                row[c] = hd; row[cin + c] = hd; row[2 * cin + c] = tl;
+            }
+}
+
 inline int perm_row_to_cout(int rho) {   // LDS/MFMA row -> channel inside a 32-row group (kernels.h)
     return (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
 }
 
 // stem: (64,3,7,7) fp32 folded -> [kh][rho][j=0..7][c=0..3] bf16, j = kw + 1, zero elsewhere
-void pack_stem(const float* wf, std::vector<uint16_t>& out) {
+void pack_stem(const float* wf, std::vector<uint16_t>& out, int part = 0) {   // part: 0 = bf16(w), 1 = tail bf16(w - head)
     out.assign((size_t)7 * 64 * 32, 0);
     for (int kh = 0; kh < 7; ++kh)
         for (int rho = 0; rho < 64; ++rho) {
             const int o = perm_row_to_cout(rho);
             for (int kw = 0; kw < 7; ++kw)
                 for (int c = 0; c < 3; ++c)
-                    out[(((size_t)kh * 64 + rho) * 8 + (kw + 1)) * 4 + c] =
-                        f32_to_bf16_rne(wf[(((size_t)o * 3 + c) * 7 + kh) * 7 + kw]);
+                {
+                    const float w = wf[(((size_t)o * 3 + c) * 7 + kh) * 7 + kw];
+                    const uint16_t hd = f32_to_bf16_rne(w);
+                    out[(((size_t)kh * 64 + rho) * 8 + (kw + 1)) * 4 + c] = part ? f32_to_bf16_rne(w - bf16_to_f32(hd)) : hd;
+                }
         }
 }
 
@@ -173,13 +201,13 @@ FastDiv make_fast_div(unsigned d) {
 constexpr int kPersistBit = 32;
 int g_num_cus = 0;
 
-template <int BC, int BP, int WC, int WP, int NSTAGE>
+template <int BC, int BP, int WC, int WP, int NSTAGE, bool SPLIT = false>
 hipError_t launch_igemm_t(ConvArgs a, bool persistent, hipStream_t s) {
     a.n_ctiles = a.Cout / BC;
     a.n_blocks = a.n_ctiles * ((a.M + BP - 1) / BP);
     a.div_ctiles = make_fast_div((unsigned)a.n_ctiles);
     const size_t lds = (size_t)NSTAGE * (BC + BP) * 128;
-    auto kern = igemm_bf16_kernel<BC, BP, WC, WP, NSTAGE>;
+    auto kern = igemm_bf16_kernel<BC, BP, WC, WP, NSTAGE, SPLIT>;
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -221,7 +249,7 @@ constexpr TunedTile kTuned[] = {
 };
 
 int auto_tile(const ConvArgs& a) {
-    if (a.N >= 96 && a.H == a.W)
+    if (a.N >= 48 && a.H == a.W)
         for (const TunedTile& t : kTuned)
             if (t.h == a.H && t.cin == a.Cin && t.cout == a.Cout && t.ks == a.ks && t.stride == a.stride &&
                 t.res == (a.res != nullptr))
@@ -231,7 +259,11 @@ int auto_tile(const ConvArgs& a) {
     return 1;
 }
 
-hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s) {
+hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s, bool split = false) {
+    if (split) {       // fp32-class mode: two tile shapes are enough (it is the accuracy path, not the fast one)
+        if (a.Cout % 128) return launch_igemm_t<64, 128, 1, 4, 2, true>(a, false, s);
+        return launch_igemm_t<128, 128, 2, 2, 2, true>(a, false, s);
+    }
     if (tile == 0) tile = auto_tile(a);
     const bool pers = (tile & kPersistBit) != 0;
     switch (tile & (kPersistBit - 1)) {
@@ -247,7 +279,7 @@ hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s) {
 }
 
 int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, const void* wt, const float* bias,
-                   const void* res, void* y, int cout, int ks, int stride, int pad, int relu) {
+                   const void* res, void* y, int cout, int ks, int stride, int pad, int relu, bool split = false) {
     if (!x || !wt || !bias || !y) return R50_ERR_INVALID;
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cin % 64 || cout <= 0 || cout % 64) return R50_ERR_INVALID;
     if (!(ks == 1 || ks == 3) || stride < 1 || pad < 0 || 2 * pad > ks - 1) return R50_ERR_INVALID;
@@ -262,15 +294,20 @@ int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, con
     if (M > (1ll << 30) || (long long)n * h * w * cin > (1ll << 31) - 1 || M * cout > (1ll << 31) - 1)
         return R50_ERR_INVALID;
     a.M = (int)M; a.HoWo = a.Ho * a.Wo;
-    a.cin_chunks = cin / 64; a.nk = ks * ks * a.cin_chunks; a.Ktot = ks * ks * cin;
+    // split mode: X is [head(cin) | tail(cin)] per pixel, K per tap is 3*cin, Y is [head(cout) | tail(cout)]
+    a.x_cstride = split ? 2 * cin : cin;
+    a.y_cstride = split ? 2 * cout : cout;
+    a.x_wrap = split ? 2 * (cin / 64) : (1 << 30);
+    a.cin_chunks = (split ? 3 : 1) * (cin / 64); a.nk = ks * ks * a.cin_chunks; a.Ktot = ks * ks * (split ? 3 : 1) * cin;
     a.n_ctiles = 0; a.n_blocks = 0;
     // buffer descriptors of the kernel (kernels.h): every offset must stay below 2^31
-    const long long x_bytes = (long long)n * h * w * cin * 2;
-    a.x_back = (pad * w + pad) * cin * 2;
-    if (x_bytes + a.x_back >= (1ll << 31) || (long long)cout * a.Ktot * 2 >= (1ll << 31)) return R50_ERR_INVALID;
+    const long long x_bytes = (long long)n * h * w * a.x_cstride * 2;
+    a.x_back = (pad * w + pad) * a.x_cstride * 2;
+    if (x_bytes + a.x_back >= (1ll << 31) || (long long)cout * a.Ktot * 2 >= (1ll << 31) || M * a.y_cstride * 2 >= (1ll << 31))
+        return R50_ERR_INVALID;
     a.x_records = (unsigned)(x_bytes + a.x_back);
     a.w_bytes = (unsigned)((long long)cout * a.Ktot * 2);
-    a.y_bytes = (unsigned)(M * cout * 2);
+    a.y_bytes = (unsigned)(M * a.y_cstride * 2);
     a.div_howo = make_fast_div((unsigned)a.HoWo);
     a.div_wo = make_fast_div((unsigned)a.Wo);
     a.div_ctiles = FastDiv{0u, 0u};
@@ -298,13 +335,14 @@ void prof_end(r50_handle* h, hipStream_t s, EvRec& r) {
 int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, int ww, const __bf16* res,
              __bf16* y, int relu, hipStream_t s, int* ho, int* wo) {
     ConvArgs a;
-    int rc = fill_conv_args(a, x, n, hh, ww, L.cin, L.w, L.bias, res, y, L.cout, L.ks, L.stride, L.pad, relu);
+    const bool split = (h->precision == R50_PREC_FP32X);
+    int rc = fill_conv_args(a, x, n, hh, ww, L.cin, L.w, L.bias, res, y, L.cout, L.ks, L.stride, L.pad, relu, split);
     if (rc) return fail(h, rc, "conv args invalid for " + L.conv_key);
     EvRec r{};
     const double flops = 2.0 * a.M * (double)a.Cout * a.Ktot;
     const double bytes = 2.0 * ((double)n * hh * ww * L.cin + (double)a.M * a.Cout * (res ? 2 : 1) + (double)a.Cout * a.Ktot);
     prof_begin(h, s, r, PC_IGEMM, flops, bytes);
-    hipError_t e = launch_igemm(a, h->tile_override, s);
+    hipError_t e = launch_igemm(a, h->tile_override, s, split);
     prof_end(h, s, r);
     if (e != hipSuccess) return fail(h, R50_ERR_HIP, "igemm launch (" + L.conv_key + "): " + hipGetErrorString(e));
     *ho = a.Ho; *wo = a.Wo;
@@ -321,6 +359,36 @@ hipError_t launch_stem_pack(const float* x, void* xp, int n, hipStream_t s) {
 hipError_t launch_stem_conv(const void* xp, const void* wpk, const float* bias, void* y, int n, hipStream_t s) {
     hipLaunchKernelGGL(stem_conv_kernel, dim3(n * (112 / STEM_ROWS_PER_WG)), dim3(256), STEM_LDS_BYTES, s,
                        (const char*)xp, (const char*)wpk, bias, (__bf16*)y);
+    return hipGetLastError();
+}
+hipError_t launch_stem_split(const float* x, char* xp_head, char* xp_tail, const char* w_head, const char* w_tail,
+                             const float* bias, void* y, int n, hipStream_t s) {
+    const long long total = (long long)n * STEM_HP * STEM_WP;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(stem_pack_split_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (u32x2*)xp_head, (u32x2*)xp_tail, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            STEM_SPLIT_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(stem_conv_split_kernel, dim3(n * (112 / STEM_ROWS_PER_WG)), dim3(256), STEM_SPLIT_LDS_BYTES, s,
+                       (const char*)xp_head, (const char*)xp_tail, w_head, w_tail, bias, (__bf16*)y);
+    return hipGetLastError();
+}
+hipError_t launch_maxpool_split(const void* x, void* y, int n, int h, int w, int c, hipStream_t s) {
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)n * ho * wo * (c / 8);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(maxpool3x3s2_split_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)x, (__bf16*)y, n, h, w,
+                       c, ho, wo);
+    return hipGetLastError();
+}
+hipError_t launch_avgpool_split(const void* x, float* y, int n, int hw, int c, hipStream_t s) {
+    const int total = n * (c / 8);
+    hipLaunchKernelGGL(avgpool_split_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const __bf16*)x, y, n, hw, c,
+                       1.0f / (float)hw);
     return hipGetLastError();
 }
 hipError_t launch_maxpool(const void* x, void* y, int n, int h, int w, int c, hipStream_t s) {
@@ -342,32 +410,48 @@ hipError_t launch_avgpool(const void* x, float* y, int n, int hw, int c, hipStre
 // Runs `n` frames (n <= max_batch) through the stack.  If `tap` is non-null, stops once the named
 // activation is available and reports it through tap_ptr / dims.
 int run_stack(r50_handle* h, const float* x, int n, float* out, hipStream_t s, const char* tap,
-              const __bf16** tap_ptr, int64_t dims[4]) {
+              const __bf16** tap_ptr, int64_t dims[4], int slot0 = 0) {
+    // slot0: first frame slot of the workspace this call may use (concurrent calls on different streams
+    // work on disjoint frame ranges of the same buffers)
+    const bool split = (h->precision == R50_PREC_FP32X);
+    const int cmul = split ? 2 : 1;            // channels per pixel multiplier of every activation tensor
+    __bf16* buf[5];
+    for (int i = 0; i < 5; ++i) buf[i] = h->buf[i] + (size_t)slot0 * 112 * 112 * 64 * cmul;
+    char* stem_xp = h->stem_xp + (size_t)slot0 * STEM_HP * STEM_WP * 8 * cmul;
     auto hit = [&](const std::string& name, const __bf16* p, int hh, int ww, int c) {
         if (tap && name == tap) {
-            *tap_ptr = p; dims[0] = n; dims[1] = hh; dims[2] = ww; dims[3] = c;
+            *tap_ptr = p; dims[0] = n; dims[1] = hh; dims[2] = ww; dims[3] = c * cmul;
             return true;
         }
         return false;
     };
     EvRec r{};
-    prof_begin(h, s, r, PC_STEM_PACK, 0, (double)n * (3.0 * 224 * 224 * 4 + (double)STEM_HP * STEM_WP * 8));
-    hipError_t e = launch_stem_pack(x, h->stem_xp, n, s);
-    prof_end(h, s, r);
-    if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem_pack: ") + hipGetErrorString(e));
+    hipError_t e;
+    if (split) {
+        char* xp_tail = stem_xp + (size_t)n * STEM_HP * STEM_WP * 8;
+        prof_begin(h, s, r, PC_STEM_CONV, 2.0 * n * 112 * 112 * 64 * 147.0, (double)n * (3.0 * 224 * 224 * 4 + 112.0 * 112 * 128 * 2));
+        e = launch_stem_split(x, stem_xp, xp_tail, h->stem_w, h->stem_w + STEM_W_BYTES, h->convs[0].bias, buf[0], n, s);
+        prof_end(h, s, r);
+        if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem (split): ") + hipGetErrorString(e));
+    } else {
+        prof_begin(h, s, r, PC_STEM_PACK, 0, (double)n * (3.0 * 224 * 224 * 4 + (double)STEM_HP * STEM_WP * 8));
+        e = launch_stem_pack(x, stem_xp, n, s);
+        prof_end(h, s, r);
+        if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem_pack: ") + hipGetErrorString(e));
 
-    prof_begin(h, s, r, PC_STEM_CONV, 2.0 * n * 112 * 112 * 64 * 147.0,
-               (double)n * ((double)STEM_HP * STEM_WP * 8 + 112.0 * 112 * 64 * 2));
-    e = launch_stem_conv(h->stem_xp, h->stem_w, h->convs[0].bias, h->buf[0], n, s);
-    prof_end(h, s, r);
-    if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem_conv: ") + hipGetErrorString(e));
-    if (hit("stem", h->buf[0], 112, 112, 64)) return R50_OK;
+        prof_begin(h, s, r, PC_STEM_CONV, 2.0 * n * 112 * 112 * 64 * 147.0,
+                   (double)n * ((double)STEM_HP * STEM_WP * 8 + 112.0 * 112 * 64 * 2));
+        e = launch_stem_conv(stem_xp, h->stem_w, h->convs[0].bias, buf[0], n, s);
+        prof_end(h, s, r);
+        if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem_conv: ") + hipGetErrorString(e));
+    }
+    if (hit("stem", buf[0], 112, 112, 64)) return R50_OK;
 
-    prof_begin(h, s, r, PC_MAXPOOL, 0, (double)n * (112.0 * 112 + 56.0 * 56) * 64 * 2);
-    e = launch_maxpool(h->buf[0], h->buf[1], n, 112, 112, 64, s);
+    prof_begin(h, s, r, PC_MAXPOOL, 0, (double)n * (112.0 * 112 + 56.0 * 56) * 64 * 2 * cmul);
+    e = split ? launch_maxpool_split(buf[0], buf[1], n, 112, 112, 64, s) : launch_maxpool(buf[0], buf[1], n, 112, 112, 64, s);
     prof_end(h, s, r);
     if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("maxpool: ") + hipGetErrorString(e));
-    if (hit("pool", h->buf[1], 56, 56, 64)) return R50_OK;
+    if (hit("pool", buf[1], 56, 56, 64)) return R50_OK;
 
     int cur = 1, hh = 56, ww = 56;
     size_t li = 1;
@@ -382,31 +466,31 @@ int run_stack(r50_handle* h, const float* x, int n, float* out, hipStream_t s, c
             const ConvLayer& c2 = h->convs[li + 1];
             const ConvLayer& c3 = h->convs[li + 2];
             int h1, w1, h2, w2, h3, w3;
-            int rc = run_conv(h, c1, h->buf[cur], n, hh, ww, nullptr, h->buf[fr[0]], 1, s, &h1, &w1);
+            int rc = run_conv(h, c1, buf[cur], n, hh, ww, nullptr, buf[fr[0]], 1, s, &h1, &w1);
             if (rc) return rc;
-            if (hit(p + ".t1", h->buf[fr[0]], h1, w1, c1.cout)) return R50_OK;
-            rc = run_conv(h, c2, h->buf[fr[0]], n, h1, w1, nullptr, h->buf[fr[1]], 1, s, &h2, &w2);
+            if (hit(p + ".t1", buf[fr[0]], h1, w1, c1.cout)) return R50_OK;
+            rc = run_conv(h, c2, buf[fr[0]], n, h1, w1, nullptr, buf[fr[1]], 1, s, &h2, &w2);
             if (rc) return rc;
-            if (hit(p + ".t2", h->buf[fr[1]], h2, w2, c2.cout)) return R50_OK;
-            const __bf16* idn = h->buf[cur];
+            if (hit(p + ".t2", buf[fr[1]], h2, w2, c2.cout)) return R50_OK;
+            const __bf16* idn = buf[cur];
             if (b == 0) {
                 const ConvLayer& cd = h->convs[li + 3];
                 int hd, wd;
-                rc = run_conv(h, cd, h->buf[cur], n, hh, ww, nullptr, h->buf[fr[2]], 0, s, &hd, &wd);
+                rc = run_conv(h, cd, buf[cur], n, hh, ww, nullptr, buf[fr[2]], 0, s, &hd, &wd);
                 if (rc) return rc;
-                if (hit(p + ".ds", h->buf[fr[2]], hd, wd, cd.cout)) return R50_OK;
-                idn = h->buf[fr[2]];
+                if (hit(p + ".ds", buf[fr[2]], hd, wd, cd.cout)) return R50_OK;
+                idn = buf[fr[2]];
             }
-            rc = run_conv(h, c3, h->buf[fr[1]], n, h2, w2, idn, h->buf[fr[3]], 1, s, &h3, &w3);
+            rc = run_conv(h, c3, buf[fr[1]], n, h2, w2, idn, buf[fr[3]], 1, s, &h3, &w3);
             if (rc) return rc;
             cur = fr[3]; hh = h3; ww = w3;
-            if (hit(p, h->buf[cur], hh, ww, c3.cout)) return R50_OK;
+            if (hit(p, buf[cur], hh, ww, c3.cout)) return R50_OK;
             li += (b == 0) ? 4 : 3;
         }
     }
     if (tap) return fail(h, R50_ERR_INVALID, std::string("unknown layer name: ") + tap);
     prof_begin(h, s, r, PC_AVGPOOL, 0, (double)n * (hh * ww * 2048.0 * 2 + 2048.0 * 4));
-    e = launch_avgpool(h->buf[cur], out, n, hh * ww, 2048, s);
+    e = split ? launch_avgpool_split(buf[cur], out, n, hh * ww, 2048, s) : launch_avgpool(buf[cur], out, n, hh * ww, 2048, s);
     prof_end(h, s, r);
     if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("avgpool: ") + hipGetErrorString(e));
     return R50_OK;
@@ -421,6 +505,13 @@ void free_all(r50_handle* h) {
     if (h->stem_w) (void)hipFree(h->stem_w);
     if (h->stem_xp) (void)hipFree(h->stem_xp);
     for (auto& b : h->buf) { if (b) (void)hipFree(b); b = nullptr; }
+    for (int i = 0; i < 4; ++i) {
+        if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+        h->side[i] = nullptr; h->ev_join[i] = nullptr;
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    h->ev_fork = nullptr;
     for (auto& r : h->ev_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& e : h->ev_free) (void)hipEventDestroy(e);
     h->ev_pending.clear(); h->ev_free.clear();
@@ -438,7 +529,9 @@ const char* r50_last_error(r50_handle* h) { return h ? h->err.c_str() : g_err.c_
 int r50_create(r50_handle** out, int device_id, int precision, int max_batch) {
     if (!out) return fail(nullptr, R50_ERR_INVALID, "r50_create: out is null");
     *out = nullptr;
-    if (precision != R50_PREC_BF16) return fail(nullptr, R50_ERR_INVALID, "r50_create: unsupported precision");
+    if (precision != R50_PREC_BF16 && precision != R50_PREC_FP32X)
+        return fail(nullptr, R50_ERR_INVALID, "r50_create: unsupported precision");
+    const int cmul = (precision == R50_PREC_FP32X) ? 2 : 1;
     if (max_batch < 1 || max_batch > 1024) return fail(nullptr, R50_ERR_INVALID, "r50_create: max_batch must be in [1,1024]");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -453,11 +546,11 @@ int r50_create(r50_handle** out, int device_id, int precision, int max_batch) {
     h->device = device_id; h->precision = precision; h->max_batch = max_batch;
     h->convs = make_specs();
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = kProfNames[i];
-    h->buf_bytes = (size_t)max_batch * 112 * 112 * 64 * 2;
+    h->buf_bytes = (size_t)max_batch * 112 * 112 * 64 * 2 * cmul;
     bool ok = true;
     for (int i = 0; i < 5 && ok; ++i) ok = hipMalloc((void**)&h->buf[i], h->buf_bytes) == hipSuccess;
-    ok = ok && hipMalloc((void**)&h->stem_xp, (size_t)max_batch * STEM_HP * STEM_WP * 8) == hipSuccess;
-    ok = ok && hipMalloc((void**)&h->stem_w, STEM_W_BYTES) == hipSuccess;
+    ok = ok && hipMalloc((void**)&h->stem_xp, (size_t)max_batch * STEM_HP * STEM_WP * 8 * cmul) == hipSuccess;
+    ok = ok && hipMalloc((void**)&h->stem_w, STEM_W_BYTES * cmul) == hipSuccess;
     if (!ok) {
         free_all(h);
         delete h;
@@ -508,11 +601,17 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
         fold_bn(w, g, b, m, v, L.cout, per_out, wf, bf);
         if (!L.bias) HIP_TRY(h, hipMalloc((void**)&L.bias, L.cout * sizeof(float)));
         HIP_TRY(h, hipMemcpy(L.bias, bf.data(), L.cout * sizeof(float), hipMemcpyHostToDevice));
+        const bool split = (h->precision == R50_PREC_FP32X);
         if (i == 0) {
-            pack_stem(wf.data(), pk);
+            pack_stem(wf.data(), pk, 0);
             HIP_TRY(h, hipMemcpy(h->stem_w, pk.data(), STEM_W_BYTES, hipMemcpyHostToDevice));
+            if (split) {
+                pack_stem(wf.data(), pk, 1);
+                HIP_TRY(h, hipMemcpy(h->stem_w + STEM_W_BYTES, pk.data(), STEM_W_BYTES, hipMemcpyHostToDevice));
+            }
         } else {
-            pack_ohwi_bf16(wf.data(), L.cout, L.cin, L.ks, pk);
+            if (split) pack_ohwi_split(wf.data(), L.cout, L.cin, L.ks, pk);
+            else pack_ohwi_bf16(wf.data(), L.cout, L.cin, L.ks, pk);
             if (!L.w) HIP_TRY(h, hipMalloc((void**)&L.w, pk.size() * 2));
             HIP_TRY(h, hipMemcpy(L.w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
         }
@@ -529,11 +628,31 @@ int r50_forward(r50_handle* h, const float* x, int n, float* out, void* stream) 
     HIP_TRY(h, hipSetDevice(h->device));
     int chunk = h->max_batch;
     if (h->micro_batch > 0 && h->micro_batch < chunk) chunk = h->micro_batch;
+    hipStream_t user = (hipStream_t)stream;
     for (int i = 0; i < n; i += chunk) {
         const int m = (n - i < chunk) ? (n - i) : chunk;
-        int rc = run_stack(h, x + (size_t)i * 3 * 224 * 224, m, out + (size_t)i * 2048, (hipStream_t)stream,
-                           nullptr, nullptr, nullptr);
-        if (rc) return rc;
+        const int ns = (h->n_streams > 1 && m >= 2 * h->n_streams) ? h->n_streams : 1;
+        if (ns == 1) {
+            int rc = run_stack(h, x + (size_t)i * 3 * 224 * 224, m, out + (size_t)i * 2048, user, nullptr, nullptr, nullptr);
+            if (rc) return rc;
+            continue;
+        }
+        // fork: the side streams start after everything already queued on the caller's stream
+        if (!h->ev_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(h->ev_fork, user));
+        const int per = (m + ns - 1) / ns;
+        for (int k = 0; k < ns; ++k) {
+            const int f0 = k * per, cnt = (m - f0 < per) ? (m - f0) : per;
+            if (cnt <= 0) break;
+            if (!h->side[k]) HIP_TRY(h, hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+            if (!h->ev_join[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
+            HIP_TRY(h, hipStreamWaitEvent(h->side[k], h->ev_fork, 0));
+            int rc = run_stack(h, x + (size_t)(i + f0) * 3 * 224 * 224, cnt, out + (size_t)(i + f0) * 2048, h->side[k],
+                               nullptr, nullptr, nullptr, f0);
+            if (rc) return rc;
+            HIP_TRY(h, hipEventRecord(h->ev_join[k], h->side[k]));
+            HIP_TRY(h, hipStreamWaitEvent(user, h->ev_join[k], 0));    // join
+        }
     }
     return R50_OK;
 }
@@ -560,6 +679,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     if (k == "micro_batch") { if (value < 0) return fail(h, R50_ERR_INVALID, "micro_batch < 0"); h->micro_batch = (int)value; }
     else if (k == "profile") h->profile = value ? 1 : 0;
     else if (k == "tile") h->tile_override = (int)value;
+    else if (k == "streams") { if (value < 1 || value > 4) return fail(h, R50_ERR_INVALID, "streams must be in [1,4]"); h->n_streams = (int)value; }
     else return fail(h, R50_ERR_INVALID, "r50_set_option: unknown key " + k);
     return R50_OK;
 }
@@ -570,6 +690,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     if (k == "micro_batch") *value = h->micro_batch;
     else if (k == "profile") *value = h->profile;
     else if (k == "tile") *value = h->tile_override;
+    else if (k == "streams") *value = h->n_streams;
     else if (k == "max_batch") *value = h->max_batch;
     else if (k == "workspace_bytes") *value = (int64_t)(5 * h->buf_bytes + (size_t)h->max_batch * STEM_HP * STEM_WP * 8);
     else return fail(h, R50_ERR_INVALID, "r50_get_option: unknown key " + k);

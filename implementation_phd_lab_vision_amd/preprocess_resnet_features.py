@@ -15,7 +15,7 @@ The clip dataset is the reference's own ``Human36MPreprocessedClips`` (src/datas
 ``$H36M_REFERENCE_SRC`` or ``sys.path`` — the frame producer is upstream of this path.  Extra,
 optional flags (defaults keep the reference behaviour): ``--weights`` (local torchvision checkpoint;
 otherwise seeded synthetic weights — nothing is downloaded), ``--synthetic-clips N`` (run without
-H36M data), ``--micro-batch``, ``--max-batch``.
+H36M data), ``--precision {bf16,fp32x}``, ``--micro-batch``, ``--max-batch``.
 """
 from __future__ import annotations
 
@@ -54,6 +54,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--weights", type=str, default=None, help="Local torchvision resnet50-*.pth (default: seeded synthetic)")
     p.add_argument("--weights-seed", type=int, default=0)
     p.add_argument("--synthetic-clips", type=int, default=0, help="Use N synthetic clips instead of reading --root")
+    p.add_argument("--precision", choices=["bf16", "fp32x"], default="bf16",
+                   help="bf16 = the reference's CUDA autocast dtype (fast); fp32x = fp32-class accuracy (its CPU numerics), ~2.7x slower")
     p.add_argument("--micro-batch", type=int, default=0, help="Frames per pass through the layer stack (0 = auto)")
     p.add_argument("--max-batch", type=int, default=256, help="Frames per backbone call chunk (workspace size)")
     return p
@@ -240,7 +242,7 @@ def main(argv: Optional[List[str]] = None) -> None:
         torch.distributed.barrier()
     ds = _open_dataset(args)
     backbone = ResNet50Backbone(weights_path=args.weights, seed=args.weights_seed, max_batch=args.max_batch,
-                                micro_batch=args.micro_batch).to(device).eval()
+                                micro_batch=args.micro_batch, precision=args.precision).to(device).eval()
 
     log("Warming up the HIP kernels...")                               # reference warm-up: :235-245
     warm = torch.zeros((min(args.max_batch, args.batch_size * args.seq_len), 3, 224, 224), device=device)

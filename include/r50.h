@@ -39,8 +39,11 @@ typedef enum r50_status {
 } r50_status;
 
 typedef enum r50_precision {
-    R50_PREC_BF16 = 1       /* bf16 operands, fp32 MFMA accumulation (the reference's CUDA autocast
+    R50_PREC_BF16 = 1,      /* bf16 operands, fp32 MFMA accumulation (the reference's CUDA autocast
                                dtype, src/preprocess_resnet_features.py:290-294) */
+    R50_PREC_FP32X = 2      /* fp32-class accuracy on the bf16 matrix cores: every value travels as a bf16
+                               (head, tail) pair, each conv is three bf16 MFMA products with fp32 accumulation
+                               (the reference's CPU numerics, autocast disabled, :239-241; ~3x the bf16 cost) */
 } r50_precision;
 
 /* One host tensor handed to r50_load_weights: torchvision state-dict key + fp32 data. */

@@ -1,0 +1,20 @@
+"""Feature accuracy of both precisions vs the oracle views (8 seeded frames). Run on the GPU box."""
+import sys, torch
+sys.path.insert(0, '.')
+from implementation_phd_lab_vision_amd import _lib
+from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
+from implementation_phd_lab_vision_amd.weights import synthetic_frames, synthetic_state_dict
+from oracle import resnet50_oracle as O
+_lib.build_library()
+sd = synthetic_state_dict(0); x = synthetic_frames(8, seed=1234)
+f64 = O.forward_reference(sd, x, dtype=torch.float64).flatten(1)
+f32 = O.forward_reference(sd, x).flatten(1)
+emu = O.forward_bf16_emulated(sd, x)
+print("oracle fp32 vs fp64      : max per-frame rel-L2 %.3e" % float(O.per_row_rel_l2(f32, f64).max()))
+print("oracle bf16-emu vs fp64  : max per-frame rel-L2 %.3e" % float(O.per_row_rel_l2(emu, f64).max()))
+for prec in ("bf16", "fp32x"):
+    bb = ResNet50Backbone(state_dict=sd, max_batch=8, precision=prec).to("cuda:0").eval()
+    f = bb(x.to("cuda:0")).flatten(1).cpu()
+    print(f"device {prec:5s} vs fp64 ref : max per-frame rel-L2 %.3e   max-abs %.3e   (vs bf16-emu oracle %.3e)" %
+          (float(O.per_row_rel_l2(f, f64).max()), float((f.double() - f64).abs().max()), float(O.per_row_rel_l2(f, emu).max())))
+    bb.close()

@@ -127,3 +127,43 @@ def test_empty_and_errors(setup):
         bb.features(torch.zeros((1, 3, 32, 32), device="cuda:0"))
     with pytest.raises(_lib.R50Error):
         bb.layer(torch.zeros((1, 3, 224, 224), device="cuda:0"), "no_such_layer")
+
+
+# ---------------------------------------------------------------------------------------------------
+# fp32x precision: fp32-class accuracy on the bf16 matrix cores.  This is the mode that meets the
+# north-star bar "features within 1e-3 rel of the reference" against the fp32 reference view
+# (= the reference's CPU numerics, autocast disabled, src/preprocess_resnet_features.py:239-241).
+# Tolerance: per-frame rel-L2 < 1e-3 on features, rel-L2 < 1e-3 on every named activation (measured ~1e-5).
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def setup_fp32x(lib_built):
+    from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
+    from implementation_phd_lab_vision_amd.weights import synthetic_frames, synthetic_state_dict
+    from oracle import resnet50_oracle as O
+    sd = synthetic_state_dict(0)
+    x = synthetic_frames(3, seed=77)
+    taps = {}
+    feats_ref = O.forward_reference(sd, x, dtype=torch.float64, taps=taps).flatten(1)
+    bb = ResNet50Backbone(state_dict=sd, max_batch=4, precision="fp32x").to("cuda:0").eval()
+    return bb, x, taps, feats_ref
+
+
+def test_fp32x_features_within_1e3_of_fp32_reference(setup_fp32x):
+    from oracle.resnet50_oracle import per_row_rel_l2
+    bb, x, _taps, feats_ref = setup_fp32x
+    f = bb(x.to("cuda:0")).flatten(1).cpu()
+    assert torch.isfinite(f).all()
+    r = per_row_rel_l2(f, feats_ref)
+    assert float(r.max()) < 1e-3, r
+
+
+def test_fp32x_named_activations(setup_fp32x):
+    from oracle.resnet50_oracle import rel_l2
+    bb, x, taps, _ = setup_fp32x
+    xd = x.to("cuda:0")
+    for name in ["stem", "pool", "layer1.0", "layer1.2", "layer2.0", "layer2.3", "layer3.5", "layer4.0", "layer4.2"]:
+        got = bb.layer(xd, name).cpu().permute(0, 3, 1, 2)
+        ref = taps[name]
+        assert got.shape == ref.shape, name
+        r = rel_l2(got, ref)
+        assert r < 1e-3, f"{name}: rel-L2 {r}"
