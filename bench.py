@@ -86,6 +86,7 @@ def main() -> None:
     ap.add_argument("--streams", type=int, default=0, help="internal streams the batch is split over (0 = library default)")
     ap.add_argument("--precision", choices=["bf16", "fp32x"], default="bf16",
                     help="bf16 = headline path; fp32x = fp32-class accuracy mode (bf16 head/tail pairs, 3 products per conv)")
+    ap.add_argument("--no-fused-stem", action="store_true", help="A/B: run conv1 / maxpool as separate kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -120,6 +121,8 @@ def main() -> None:
     bb = ResNet50Backbone(state_dict=sd, max_batch=args.batch, micro_batch=args.micro_batch, precision=args.precision).to(dev).eval()
     if args.streams:
         bb.set_option("streams", args.streams)
+    if args.no_fused_stem:
+        bb.set_option("fused_stem", 0)
     x = synthetic_frames(args.batch, seed=1234 + rank).to(dev)          # random data, resident in HBM
     feats = torch.empty((args.batch, 2048), dtype=torch.float32, device=dev)
     gathered = [torch.empty_like(feats) for _ in range(world)] if (dist is not None and rank == 0) else None
@@ -152,6 +155,8 @@ def main() -> None:
     roofline = None
     kernels = None
     if rank == 0:
+        n_streams = bb.get_option("streams")
+        bb.set_option("streams", 1)          # one stream: event brackets must not interleave with another stream's kernels
         bb.set_option("profile", 1)
         bb.profile_reset()
         for _ in range(args.steps):
@@ -159,6 +164,7 @@ def main() -> None:
         torch.cuda.synchronize(dev)
         prof = bb.profile_collect()
         bb.set_option("profile", 0)
+        bb.set_option("streams", n_streams)
         ig = prof["igemm"]
         achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         traffic = None          # HBM bytes per igemm launch from rocprofv3 PMC passes (scripts/pmc_bench.sh), committed

@@ -528,6 +528,162 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const __bf16* __restrict__
     *reinterpret_cast<f32x4*>(o + 4) = (f32x4){s[4] * inv_hw, s[5] * inv_hw, s[6] * inv_hw, s[7] * inv_hw};
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused stem (bf16 mode): fp32 NCHW frame -> [pack to bf16 NHWC4 in LDS] -> conv1 7x7 s2 + bias + ReLU
+// -> [conv rows in LDS] -> MaxPool2d(3,2,1) -> (N,56,56,64) bf16 NHWC.  Replaces stem_pack + stem_conv +
+// maxpool: the 112x112x64 conv1 activation (1.6 MB/frame written and read back) never touches HBM and
+// the packed image is never materialised.
+// Workgroup = one image x 2 pooled rows (r0, r0+1): conv rows 2*r0-1 .. 2*r0+3 (5 waves, one conv row
+// each), input rows 4*r0-5 .. 4*r0+9 (15 rows; rows outside the image are zero = conv padding, conv
+// rows/cols outside 0..111 are skipped = -inf pool padding).
+// LDS: weights 28,672 B | input 15 x 1,856 B | conv out 5 x 112 x 128 B (16-B chunk c of pixel wo at c ^ (wo&7)).
+// ------------------------------------------------------------------------------------------------
+constexpr int SF_IN_ROWS = 15;
+constexpr int SF_CONV_ROWS = 5;
+constexpr int SF_IN_BYTES = SF_IN_ROWS * STEM_ROW_BYTES;
+constexpr int SF_OUT_BYTES = SF_CONV_ROWS * 112 * 128;
+constexpr int SF_LDS_BYTES = STEM_W_BYTES + SF_IN_BYTES + SF_OUT_BYTES;
+constexpr int SF_THREADS = 512;                       // 8 waves: 5 of them run the MFMAs, all 8 pack and pool
+constexpr int SF_PACK_ROWS = 8;                       // rows per packing thread: threads [0,232) rows 0-7, [232,464) rows 8-14
+
+__device__ __forceinline__ unsigned max_bf16x2_nonneg(unsigned a, unsigned b) {   // both operands >= +0: integer order = float order
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+
+__global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const float* __restrict__ x, const char* __restrict__ wpk,
+                                                                const float* __restrict__ bias, __bf16* __restrict__ y,
+                                                                int n_tiles) {
+    // Persistent: workgroup b handles tiles b, b + grid, ... (tile = image x pooled-row pair).  The fp32 pixels
+    // of tile t+1 are loaded into registers while tile t runs its MFMAs and pooling; the weights are staged once.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w = smem;
+    char* s_in = smem + STEM_W_BYTES;
+    char* s_out = smem + STEM_W_BYTES + SF_IN_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+
+    for (int c = tid; c < STEM_W_BYTES / 16; c += SF_THREADS)
+        *reinterpret_cast<u32x4*>(s_w + c * 16) = *reinterpret_cast<const u32x4*>(wpk + c * 16);
+
+    // packing role: one padded column wp (wi = wp - 4) x 8 (or 7) consecutive input rows
+    const int p_half = tid >= STEM_WP ? 1 : 0;
+    const int p_wp = tid - p_half * STEM_WP;
+    const bool p_active = tid < 2 * STEM_WP;
+    const bool p_col_ok = p_active && (unsigned)(p_wp - 4) < 224u;
+    float pc[SF_PACK_ROWS][3];
+    auto load_tile = [&](int tile) {
+        const int n = tile / 28;
+        const int in0 = 4 * ((tile % 28) * 2) - 5 + p_half * SF_PACK_ROWS;    // first input row of this thread
+        const float* base = x + (size_t)n * 3 * 224 * 224 + (p_col_ok ? p_wp - 4 : 0);
+#pragma unroll
+        for (int r = 0; r < SF_PACK_ROWS; ++r) {
+            const int hi = in0 + r;
+            const bool ok = p_col_ok && (unsigned)hi < 224u && (p_half * SF_PACK_ROWS + r) < SF_IN_ROWS;
+            const float* p = base + (ok ? hi * 224 : 0);
+            pc[r][0] = ok ? p[0] : 0.f;
+            pc[r][1] = ok ? p[224 * 224] : 0.f;
+            pc[r][2] = ok ? p[2 * 224 * 224] : 0.f;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < n_tiles) load_tile(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int n = tile / 28;
+        const int r0 = (tile % 28) * 2;                // first pooled row
+        // registers -> s_in[row][wp][4] bf16 (zero border / zero rows outside the image)
+        if (p_active) {
+#pragma unroll
+            for (int r = 0; r < SF_PACK_ROWS; ++r) {
+                const int row = p_half * SF_PACK_ROWS + r;
+                if (row < SF_IN_ROWS)
+                    *reinterpret_cast<u32x2*>(s_in + (row * STEM_WP + p_wp) * 8) =
+                        (u32x2){pack_bf16x2(pc[r][0], pc[r][1]), pack_bf16x2(pc[r][2], 0.f)};
+            }
+        }
+        __syncthreads();                               // s_in (and, first time, s_w) ready; previous pooling finished
+        if (tile + (int)gridDim.x < n_tiles) load_tile(tile + gridDim.x);
+
+        const int crow = 2 * r0 - 1 + wave;            // conv row of waves 0..4
+        if (wave < SF_CONV_ROWS && crow >= 0 && crow < 112) {
+            f32x4 acc[4][7];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // conv row c reads input rows 2c-3+kh = (first held row) + 2*wave + kh
+            const int w_frag = fr * 64 + fq * 16;
+            const int x_frag = (2 * wave) * STEM_ROW_BYTES + fr * 16 + fq * 16;
+#pragma unroll
+            for (int kh = 0; kh < 7; ++kh) {
+                bf16x8 wf[4], xf[7];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(s_w + kh * 4096 + m * 1024 + w_frag);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(s_in + x_frag + kh * STEM_ROW_BYTES + j * 256);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[j], acc[m][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int cout = 32 * t + 8 * fq;
+                const f32x4 b_lo = *reinterpret_cast<const f32x4*>(bias + cout);
+                const f32x4 b_hi = *reinterpret_cast<const f32x4*>(bias + cout + 4);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const int wo = 16 * j + fr;
+                    u32x4 out;
+                    out[0] = relu_bf16x2(pack_bf16x2(acc[2 * t][j][0] + b_lo[0], acc[2 * t][j][1] + b_lo[1]));
+                    out[1] = relu_bf16x2(pack_bf16x2(acc[2 * t][j][2] + b_lo[2], acc[2 * t][j][3] + b_lo[3]));
+                    out[2] = relu_bf16x2(pack_bf16x2(acc[2 * t + 1][j][0] + b_hi[0], acc[2 * t + 1][j][1] + b_hi[1]));
+                    out[3] = relu_bf16x2(pack_bf16x2(acc[2 * t + 1][j][2] + b_hi[2], acc[2 * t + 1][j][3] + b_hi[3]));
+                    *reinterpret_cast<u32x4*>(s_out + (wave * 112 + wo) * 128 + (((4 * t + fq) ^ (wo & 7)) << 4)) = out;
+                }
+            }
+        }
+        __syncthreads();                               // conv rows complete; s_in free for the next tile
+
+        // pool: thread = (pooled column q, channel group g); horizontal 3-max of each of the 5 conv rows, then the
+        // two vertical 3-maxes (rows 0-2 and 2-4).  All values are post-ReLU (>= +0), so the maximum is taken on the
+        // packed bf16 words with integer max (v_pk_max_i16) and 0 is the identity for the padding taps.
+        if (tid < 56 * 8) {
+            const int g = tid & 7, q = tid >> 3;
+            u32x4 hrow[SF_CONV_ROWS];
+#pragma unroll
+            for (int lrow = 0; lrow < SF_CONV_ROWS; ++lrow) {
+                u32x4 h = (u32x4){0u, 0u, 0u, 0u};
+                const int c = 2 * r0 - 1 + lrow;
+                if (c >= 0 && c < 112) {
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const int wo = 2 * q - 1 + dw;
+                        if (wo >= 0) {                 // wo <= 111 always
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(s_out + (lrow * 112 + wo) * 128 + ((g ^ (wo & 7)) << 4));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) h[e] = max_bf16x2_nonneg(h[e], v[e]);
+                        }
+                    }
+                }
+                hrow[lrow] = h;
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                u32x4 out;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    out[e] = max_bf16x2_nonneg(max_bf16x2_nonneg(hrow[2 * pr][e], hrow[2 * pr + 1][e]), hrow[2 * pr + 2][e]);
+                *reinterpret_cast<u32x4*>(y + (((size_t)n * 56 + r0 + pr) * 56 + q) * 64 + g * 8) = out;
+            }
+        }
+        // the next iteration's first barrier orders this pooling against the next conv's s_out writes
+    }
+}
+
 // ================================================================================================
 // Split-precision ("fp32x") variants of the non-GEMM kernels.  In this mode every activation travels
 // as a pair of bf16 tensors (head, tail) with head + tail ~ the fp32 value (16 mantissa bits), stored

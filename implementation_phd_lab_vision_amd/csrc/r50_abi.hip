@@ -46,6 +46,7 @@ struct r50_handle {
     int micro_batch = 0;
     int profile = 0;
     int tile_override = 0;
+    int fused_stem = 1;                 // bf16 mode: conv1+bn1+relu+maxpool in one kernel
     int n_streams = 2;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -274,6 +275,9 @@ hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s, bool split =
         case 6: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 128, 4, 2, 3>(a, pers, s);
         case 7: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 256, 2, 4, 3>(a, pers, s);
         case 8: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 128, 2, 4, 3>(a, pers, s);
+        case 9: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 64, 2, 2, 3>(a, pers, s);
+        case 10: return launch_igemm_t<64, 128, 1, 4, 3>(a, pers, s);
+        case 11: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 128, 2, 2, 3>(a, pers, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -361,6 +365,25 @@ hipError_t launch_stem_conv(const void* xp, const void* wpk, const float* bias, 
                        (const char*)xp, (const char*)wpk, bias, (__bf16*)y);
     return hipGetLastError();
 }
+hipError_t launch_stem_fused(const float* x, const void* wpk, const float* bias, void* y, int n, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        g_num_cus = prop.multiProcessorCount;
+    }
+    const int tiles = n * 28;
+    const int grid = tiles < g_num_cus ? tiles : g_num_cus;       // 128 KB of LDS: one workgroup per CU
+    hipLaunchKernelGGL(stem_fused_kernel, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, tiles);
+    return hipGetLastError();
+}
 hipError_t launch_stem_split(const float* x, char* xp_head, char* xp_tail, const char* w_head, const char* w_tail,
                              const float* bias, void* y, int n, hipStream_t s) {
     const long long total = (long long)n * STEM_HP * STEM_WP;
@@ -433,6 +456,13 @@ int run_stack(r50_handle* h, const float* x, int n, float* out, hipStream_t s, c
         e = launch_stem_split(x, stem_xp, xp_tail, h->stem_w, h->stem_w + STEM_W_BYTES, h->convs[0].bias, buf[0], n, s);
         prof_end(h, s, r);
         if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem (split): ") + hipGetErrorString(e));
+    } else if (h->fused_stem && !(tap && std::string(tap) == "stem")) {
+        // conv1 + bn1 + relu + maxpool in one kernel: frame in, (n,56,56,64) out
+        prof_begin(h, s, r, PC_STEM_CONV, 2.0 * n * 112 * 112 * 64 * 147.0, (double)n * (3.0 * 224 * 224 * 4 + 56.0 * 56 * 64 * 2));
+        e = launch_stem_fused(x, h->stem_w, h->convs[0].bias, buf[1], n, s);
+        prof_end(h, s, r);
+        if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem_fused: ") + hipGetErrorString(e));
+        goto after_pool;
     } else {
         prof_begin(h, s, r, PC_STEM_PACK, 0, (double)n * (3.0 * 224 * 224 * 4 + (double)STEM_HP * STEM_WP * 8));
         e = launch_stem_pack(x, stem_xp, n, s);
@@ -451,6 +481,7 @@ int run_stack(r50_handle* h, const float* x, int n, float* out, hipStream_t s, c
     e = split ? launch_maxpool_split(buf[0], buf[1], n, 112, 112, 64, s) : launch_maxpool(buf[0], buf[1], n, 112, 112, 64, s);
     prof_end(h, s, r);
     if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("maxpool: ") + hipGetErrorString(e));
+after_pool:
     if (hit("pool", buf[1], 56, 56, 64)) return R50_OK;
 
     int cur = 1, hh = 56, ww = 56;
@@ -679,6 +710,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     if (k == "micro_batch") { if (value < 0) return fail(h, R50_ERR_INVALID, "micro_batch < 0"); h->micro_batch = (int)value; }
     else if (k == "profile") h->profile = value ? 1 : 0;
     else if (k == "tile") h->tile_override = (int)value;
+    else if (k == "fused_stem") h->fused_stem = value ? 1 : 0;
     else if (k == "streams") { if (value < 1 || value > 4) return fail(h, R50_ERR_INVALID, "streams must be in [1,4]"); h->n_streams = (int)value; }
     else return fail(h, R50_ERR_INVALID, "r50_set_option: unknown key " + k);
     return R50_OK;
@@ -691,6 +723,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "profile") *value = h->profile;
     else if (k == "tile") *value = h->tile_override;
     else if (k == "streams") *value = h->n_streams;
+    else if (k == "fused_stem") *value = h->fused_stem;
     else if (k == "max_batch") *value = h->max_batch;
     else if (k == "workspace_bytes") *value = (int64_t)(5 * h->buf_bytes + (size_t)h->max_batch * STEM_HP * STEM_WP * 8);
     else return fail(h, R50_ERR_INVALID, "r50_get_option: unknown key " + k);

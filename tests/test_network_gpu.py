@@ -167,3 +167,22 @@ def test_fp32x_named_activations(setup_fp32x):
         assert got.shape == ref.shape, name
         r = rel_l2(got, ref)
         assert r < 1e-3, f"{name}: rel-L2 {r}"
+
+
+def test_fused_stem_equals_unfused(setup):
+    """conv1+bn1+relu+maxpool fused in one kernel must equal the three-kernel path bit for bit (same K order,
+    same roundings), for every frame position incl. the image borders."""
+    from implementation_phd_lab_vision_amd import ops
+    bb, x, *_ = setup
+    xd = x.to("cuda:0")
+    assert bb.get_option("fused_stem") == 1
+    fused = bb.layer(xd, "pool")                       # fused kernel (the 'stem' tap alone forces the unfused path)
+    unfused = ops.maxpool_bf16(bb.layer(xd, "stem").contiguous())
+    assert torch.equal(fused, unfused)
+    bb.set_option("fused_stem", 0)
+    try:
+        assert torch.equal(bb.layer(xd, "pool"), unfused)
+        f0 = bb.features(xd).clone()
+    finally:
+        bb.set_option("fused_stem", 1)
+    assert torch.equal(bb.features(xd), f0)
