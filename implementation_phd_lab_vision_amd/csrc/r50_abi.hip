@@ -27,6 +27,7 @@ const char* kProfNames[PC_COUNT] = {"igemm", "conv1", "maxpool", "avgpool", "ste
 struct EvRec {
     hipEvent_t a, b;
     int cls;
+    int layer;        // index into convs (per-layer breakdown) or -1
     double flops, bytes;
 };
 
@@ -47,7 +48,7 @@ struct r50_handle {
     int profile = 0;
     int tile_override = 0;
     int fused_stem = 1;                 // bf16 mode: conv1+bn1+relu+maxpool in one kernel
-    int n_streams = 2;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
+    int n_streams = 1;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool loaded = false;
@@ -58,6 +59,7 @@ struct r50_handle {
     __bf16* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t buf_bytes = 0;
     Prof prof[PC_COUNT];
+    std::vector<Prof> prof_layer;       // one entry per conv, same order as convs
     std::vector<EvRec> ev_pending;
     std::vector<hipEvent_t> ev_free;
 };
@@ -319,8 +321,9 @@ int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, con
 }
 
 // profiling brackets
-void prof_begin(r50_handle* h, hipStream_t s, EvRec& r, int cls, double flops, double bytes) {
+void prof_begin(r50_handle* h, hipStream_t s, EvRec& r, int cls, double flops, double bytes, int layer = -1) {
     if (!h || !h->profile) return;
+    r.layer = layer;
     auto get = [&]() {
         hipEvent_t e;
         if (!h->ev_free.empty()) { e = h->ev_free.back(); h->ev_free.pop_back(); }
@@ -343,9 +346,9 @@ int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, 
     int rc = fill_conv_args(a, x, n, hh, ww, L.cin, L.w, L.bias, res, y, L.cout, L.ks, L.stride, L.pad, relu, split);
     if (rc) return fail(h, rc, "conv args invalid for " + L.conv_key);
     EvRec r{};
-    const double flops = 2.0 * a.M * (double)a.Cout * a.Ktot;
-    const double bytes = 2.0 * ((double)n * hh * ww * L.cin + (double)a.M * a.Cout * (res ? 2 : 1) + (double)a.Cout * a.Ktot);
-    prof_begin(h, s, r, PC_IGEMM, flops, bytes);
+    const double flops = 2.0 * a.M * (double)a.Cout * L.ks * L.ks * L.cin;       // algorithmic (not the 3x of split mode)
+    const double bytes = 2.0 * ((double)n * hh * ww * L.cin + (double)a.M * a.Cout * (res ? 2 : 1) + (double)a.Cout * L.ks * L.ks * L.cin);
+    prof_begin(h, s, r, PC_IGEMM, flops, bytes, (int)(&L - &h->convs[0]));
     hipError_t e = launch_igemm(a, h->tile_override, s, split);
     prof_end(h, s, r);
     if (e != hipSuccess) return fail(h, R50_ERR_HIP, "igemm launch (" + L.conv_key + "): " + hipGetErrorString(e));
@@ -577,6 +580,8 @@ int r50_create(r50_handle** out, int device_id, int precision, int max_batch) {
     h->device = device_id; h->precision = precision; h->max_batch = max_batch;
     h->convs = make_specs();
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = kProfNames[i];
+    h->prof_layer.resize(h->convs.size());
+    for (size_t i = 0; i < h->convs.size(); ++i) h->prof_layer[i].name = h->convs[i].conv_key.c_str();
     h->buf_bytes = (size_t)max_batch * 112 * 112 * 64 * 2 * cmul;
     bool ok = true;
     for (int i = 0; i < 5 && ok; ++i) ok = hipMalloc((void**)&h->buf[i], h->buf_bytes) == hipSuccess;
@@ -735,6 +740,7 @@ int r50_profile_reset(r50_handle* h) {
     for (auto& r : h->ev_pending) { h->ev_free.push_back(r.a); h->ev_free.push_back(r.b); }
     h->ev_pending.clear();
     for (int i = 0; i < PC_COUNT; ++i) { h->prof[i].launches = 0; h->prof[i].ms = h->prof[i].flops = h->prof[i].bytes = 0; }
+    for (auto& p : h->prof_layer) { p.launches = 0; p.ms = p.flops = p.bytes = 0; }
     return R50_OK;
 }
 
@@ -746,22 +752,27 @@ int r50_profile_collect(r50_handle* h) {
         HIP_TRY(h, hipEventElapsedTime(&ms, r.a, r.b));
         Prof& p = h->prof[r.cls];
         p.launches += 1; p.ms += ms; p.flops += r.flops; p.bytes += r.bytes;
+        if (r.layer >= 0 && r.layer < (int)h->prof_layer.size()) {
+            Prof& q = h->prof_layer[r.layer];
+            q.launches += 1; q.ms += ms; q.flops += r.flops; q.bytes += r.bytes;
+        }
         h->ev_free.push_back(r.a); h->ev_free.push_back(r.b);
     }
     h->ev_pending.clear();
     return R50_OK;
 }
 
-int r50_profile_count(r50_handle* h) { return h ? PC_COUNT : 0; }
+int r50_profile_count(r50_handle* h) { return h ? PC_COUNT + (int)h->prof_layer.size() : 0; }
 
 int r50_profile_entry(r50_handle* h, int i, const char** name, int64_t* launches, double* total_ms, double* flops,
                       double* bytes) {
-    if (!h || i < 0 || i >= PC_COUNT) return R50_ERR_INVALID;
-    if (name) *name = h->prof[i].name;
-    if (launches) *launches = h->prof[i].launches;
-    if (total_ms) *total_ms = h->prof[i].ms;
-    if (flops) *flops = h->prof[i].flops;
-    if (bytes) *bytes = h->prof[i].bytes;
+    if (!h || i < 0 || i >= PC_COUNT + (int)h->prof_layer.size()) return R50_ERR_INVALID;
+    const Prof& p = (i < PC_COUNT) ? h->prof[i] : h->prof_layer[i - PC_COUNT];
+    if (name) *name = p.name;
+    if (launches) *launches = p.launches;
+    if (total_ms) *total_ms = p.ms;
+    if (flops) *flops = p.flops;
+    if (bytes) *bytes = p.bytes;
     return R50_OK;
 }
 

@@ -85,7 +85,8 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value);
 /* Per-kernel timing from HIP events recorded on the launch stream while option "profile" is 1.
  * r50_profile_collect synchronises the recorded events and accumulates them; then
  * r50_profile_count / r50_profile_entry enumerate kernel classes ("igemm", "conv1", "maxpool",
- * "avgpool", "stem_pack") with launch count, total ms, algorithmic flops and bytes. */
+ * "avgpool", "stem_pack") and then one entry per bottleneck conv (named by its torchvision key, e.g.
+ * "layer3.4.conv2"; "conv1" stays in its class), with launch count, total ms, algorithmic flops and bytes. */
 int r50_profile_reset(r50_handle* h);
 int r50_profile_collect(r50_handle* h);
 int r50_profile_count(r50_handle* h);
