@@ -277,9 +277,6 @@ hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s, bool split =
         case 6: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 128, 4, 2, 3>(a, pers, s);
         case 7: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 256, 2, 4, 3>(a, pers, s);
         case 8: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 128, 2, 4, 3>(a, pers, s);
-        case 9: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 64, 2, 2, 3>(a, pers, s);
-        case 10: return launch_igemm_t<64, 128, 1, 4, 3>(a, pers, s);
-        case 11: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 128, 2, 2, 3>(a, pers, s);
         default: return hipErrorInvalidValue;
     }
 }
