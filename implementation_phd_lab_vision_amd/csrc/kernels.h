@@ -224,7 +224,9 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
 
     // ---------------- compute side ----------------------------------------------------------------
     f32x4 acc[MR][NR];
-    u32x4 res_reg[MR / 2][NR];
+    constexpr bool BIG = (MR * NR > 16);          // 128+ accumulator registers: keep the other register users small
+    constexpr bool PREFETCH_RES = !SPLIT && !BIG;
+    u32x4 res_reg[PREFETCH_RES ? MR / 2 : 1][PREFETCH_RES ? NR : 1];
     const bool has_res = (a.res != nullptr);
     const int fphys0 = (fq ^ (fr & 7)) << 4;       // kk = 0; kk = 1 is ^ 64
     const int w_frag = (wave_c * MR * 16 + fr) * 128;
@@ -247,13 +249,29 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
             for (int j = 0; j < NR; ++j) {
                 acc[2 * t][j] = b_lo;
                 acc[2 * t + 1][j] = b_hi;
-                if (!SPLIT && has_res)     // row displacement in voffset: soffset is not part of the range check
+                if constexpr (PREFETCH_RES) if (has_res)     // row displacement in voffset: soffset is not part of the range check
                     res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, 0);
             }
         }
     };
     auto compute = [&]() {
         const char* sbase = smem + c_buf * STAGE_BYTES;
+        if constexpr (BIG) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int ph = fphys0 ^ (kk << 6);
+                bf16x8 wf[MR], xf[NR];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(sbase + x_frag + j * 2048 + ph);
+#pragma unroll
+                for (int m = 0; m < MR; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(sbase + w_frag + m * 2048 + ph);
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[j], acc[m][j], 0, 0, 0);
+            }
+        } else {
         bf16x8 wf[2][MR], xf[2][NR];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -272,6 +290,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
 #pragma unroll
                 for (int j = 0; j < NR; ++j)
                     acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][m], xf[kk][j], acc[m][j], 0, 0, 0);
+        }
     };
     auto epilogue = [&]() {                        // (+ residual) -> bf16 -> ReLU on the packed pair -> 16-B store
 #pragma unroll
@@ -282,7 +301,9 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
                 const unsigned voff = y_voff + j * y_rowstep + 64 * t;
                 if constexpr (!SPLIT) {
                     if (has_res) {
-                        const u32x4 r = res_reg[t][j];
+                        u32x4 r;
+                        if constexpr (PREFETCH_RES) r = res_reg[t][j];
+                        else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, 0, 0);
                         lo[0] += bf16_bits_to_f32(r[0] & 0xffffu); lo[1] += __uint_as_float(r[0] & 0xffff0000u);
                         lo[2] += bf16_bits_to_f32(r[1] & 0xffffu); lo[3] += __uint_as_float(r[1] & 0xffff0000u);
                         hi[0] += bf16_bits_to_f32(r[2] & 0xffffu); hi[1] += __uint_as_float(r[2] & 0xffff0000u);

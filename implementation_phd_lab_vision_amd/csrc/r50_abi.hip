@@ -200,6 +200,7 @@ FastDiv make_fast_div(unsigned d) {
 // Tile-config ids of igemm_bf16_kernel (BC couts x BP pixels):
 //   4 waves, 2 LDS stages:                1 = 128x128, 2 = 64x128, 3 = 64x256, 5 = 128x64
 //   8 waves, 3 LDS stages, counted vmcnt: 6 = 256x128, 7 = 128x256, 8 = 128x128
+//   8 waves, 2 LDS stages, 128 accumulator registers: 9 = 256x256 (wave 64c x 128p), 10 = 256x256 (wave 128c x 64p)
 //   + 32: chip-sized persistent grid (tiles streamed through the LDS ring) instead of one tile per workgroup
 constexpr int kPersistBit = 32;
 int g_num_cus = 0;
@@ -244,11 +245,11 @@ hipError_t launch_igemm_t(ConvArgs a, bool persistent, hipStream_t s) {
 struct TunedTile { int h, cin, cout, ks, stride, res, tile; };
 constexpr TunedTile kTuned[] = {
     {56, 64, 64, 1, 1, 0, 34},    {56, 64, 64, 3, 1, 0, 2},     {56, 64, 256, 1, 1, 1, 39},   {56, 64, 256, 1, 1, 0, 38},
-    {56, 256, 64, 1, 1, 0, 2},    {56, 256, 128, 1, 1, 0, 40},  {56, 128, 128, 3, 2, 0, 33},  {28, 128, 512, 1, 1, 1, 40},
-    {56, 256, 512, 1, 2, 0, 38},  {28, 512, 128, 1, 1, 0, 2},   {28, 128, 128, 3, 1, 0, 33},  {28, 512, 256, 1, 1, 0, 38},
-    {28, 256, 256, 3, 2, 0, 1},   {14, 256, 1024, 1, 1, 1, 2},  {28, 512, 1024, 1, 2, 0, 1},  {14, 1024, 256, 1, 1, 0, 1},
-    {14, 256, 256, 3, 1, 0, 1},   {14, 1024, 512, 1, 1, 0, 33}, {14, 512, 512, 3, 2, 0, 33},  {7, 512, 2048, 1, 1, 1, 33},
-    {14, 1024, 2048, 1, 2, 0, 33}, {7, 2048, 512, 1, 1, 0, 1},  {7, 512, 512, 3, 1, 0, 33},
+    {56, 256, 64, 1, 1, 0, 2},    {56, 256, 128, 1, 1, 0, 40},  {56, 128, 128, 3, 2, 0, 33},  {28, 128, 512, 1, 1, 1, 39},
+    {56, 256, 512, 1, 2, 0, 42},  {28, 512, 128, 1, 1, 0, 33},  {28, 128, 128, 3, 1, 0, 37},  {28, 512, 256, 1, 1, 0, 38},
+    {28, 256, 256, 3, 2, 0, 41},  {14, 256, 1024, 1, 1, 1, 37}, {28, 512, 1024, 1, 2, 0, 41}, {14, 1024, 256, 1, 1, 0, 41},
+    {14, 256, 256, 3, 1, 0, 41},  {14, 1024, 512, 1, 1, 0, 41}, {14, 512, 512, 3, 2, 0, 33},  {7, 512, 2048, 1, 1, 1, 37},
+    {14, 1024, 2048, 1, 2, 0, 41}, {7, 2048, 512, 1, 1, 0, 33}, {7, 512, 512, 3, 1, 0, 33},
 };
 
 int auto_tile(const ConvArgs& a) {
@@ -277,6 +278,8 @@ hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s, bool split =
         case 6: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 128, 4, 2, 3>(a, pers, s);
         case 7: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 256, 2, 4, 3>(a, pers, s);
         case 8: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 128, 2, 4, 3>(a, pers, s);
+        case 9: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 256, 4, 2, 2>(a, pers, s);
+        case 10: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 256, 2, 4, 2>(a, pers, s);
         default: return hipErrorInvalidValue;
     }
 }

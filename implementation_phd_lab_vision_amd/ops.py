@@ -21,6 +21,8 @@ TILE_128x64 = 5
 TILE_256x128_P3 = 6      # 8 waves, 3 LDS stages, counted vmcnt
 TILE_128x256_P3 = 7
 TILE_128x128_P3 = 8
+TILE_256x256 = 9         # 8 waves, 2 LDS stages, wave tile 64c x 128p
+TILE_256x256_B = 10      # 8 waves, 2 LDS stages, wave tile 128c x 64p
 PERSISTENT = 32          # + PERSISTENT: chip-sized grid, tiles streamed through the LDS ring
 
 
