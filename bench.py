@@ -87,6 +87,7 @@ def main() -> None:
     ap.add_argument("--precision", choices=["bf16", "fp32x"], default="bf16",
                     help="bf16 = headline path; fp32x = fp32-class accuracy mode (bf16 head/tail pairs, 3 products per conv)")
     ap.add_argument("--no-fused-stem", action="store_true", help="A/B: run conv1 / maxpool as separate kernels")
+    ap.add_argument("--no-overlap-ds", action="store_true", help="A/B: downsample convs on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -123,6 +124,8 @@ def main() -> None:
         bb.set_option("streams", args.streams)
     if args.no_fused_stem:
         bb.set_option("fused_stem", 0)
+    if args.no_overlap_ds:
+        bb.set_option("overlap_ds", 0)
     x = synthetic_frames(args.batch, seed=1234 + rank).to(dev)          # random data, resident in HBM
     feats = torch.empty((args.batch, 2048), dtype=torch.float32, device=dev)
     gathered = [torch.empty_like(feats) for _ in range(world)] if (dist is not None and rank == 0) else None

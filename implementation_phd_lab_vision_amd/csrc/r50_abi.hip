@@ -47,6 +47,9 @@ struct r50_handle {
     int micro_batch = 0;
     int profile = 0;
     int tile_override = 0;
+    int overlap_ds = 0;                 // downsample conv of a stage's first block on a side stream
+    hipStream_t ds_stream = nullptr;
+    hipEvent_t ev_ds_fork = nullptr, ev_ds_join = nullptr;
     int fused_stem = 1;                 // bf16 mode: conv1+bn1+relu+maxpool in one kernel
     int n_streams = 1;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -500,14 +503,34 @@ after_pool:
             const ConvLayer& c2 = h->convs[li + 1];
             const ConvLayer& c3 = h->convs[li + 2];
             int h1, w1, h2, w2, h3, w3;
-            int rc = run_conv(h, c1, buf[cur], n, hh, ww, nullptr, buf[fr[0]], 1, s, &h1, &w1);
+            // The downsample branch of a stage's first block only depends on the block input: it runs on a side
+            // stream beside conv1 -> conv2 (fills the partially occupied last round of those launches).  Not while
+            // profiling (event brackets of two streams would interleave) and not when a tap is requested.
+            const bool ds_side = (b == 0) && h->overlap_ds && !h->profile && !tap;
+            hipStream_t sd = s;
+            const __bf16* idn = buf[cur];
+            int rc;
+            if (ds_side) {
+                if (!h->ds_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->ds_stream, hipStreamNonBlocking));
+                if (!h->ev_ds_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_ds_fork, hipEventDisableTiming));
+                if (!h->ev_ds_join) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_ds_join, hipEventDisableTiming));
+                sd = h->ds_stream;
+                HIP_TRY(h, hipEventRecord(h->ev_ds_fork, s));          // block input complete
+                HIP_TRY(h, hipStreamWaitEvent(sd, h->ev_ds_fork, 0));
+                const ConvLayer& cd = h->convs[li + 3];
+                int hd, wd;
+                rc = run_conv(h, cd, buf[cur], n, hh, ww, nullptr, buf[fr[2]], 0, sd, &hd, &wd);
+                if (rc) return rc;
+                HIP_TRY(h, hipEventRecord(h->ev_ds_join, sd));
+                idn = buf[fr[2]];
+            }
+            rc = run_conv(h, c1, buf[cur], n, hh, ww, nullptr, buf[fr[0]], 1, s, &h1, &w1);
             if (rc) return rc;
             if (hit(p + ".t1", buf[fr[0]], h1, w1, c1.cout)) return R50_OK;
             rc = run_conv(h, c2, buf[fr[0]], n, h1, w1, nullptr, buf[fr[1]], 1, s, &h2, &w2);
             if (rc) return rc;
             if (hit(p + ".t2", buf[fr[1]], h2, w2, c2.cout)) return R50_OK;
-            const __bf16* idn = buf[cur];
-            if (b == 0) {
+            if (b == 0 && !ds_side) {
                 const ConvLayer& cd = h->convs[li + 3];
                 int hd, wd;
                 rc = run_conv(h, cd, buf[cur], n, hh, ww, nullptr, buf[fr[2]], 0, s, &hd, &wd);
@@ -515,6 +538,7 @@ after_pool:
                 if (hit(p + ".ds", buf[fr[2]], hd, wd, cd.cout)) return R50_OK;
                 idn = buf[fr[2]];
             }
+            if (ds_side) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_ds_join, 0));   // conv3 needs the downsample output
             rc = run_conv(h, c3, buf[fr[1]], n, h2, w2, idn, buf[fr[3]], 1, s, &h3, &w3);
             if (rc) return rc;
             cur = fr[3]; hh = h3; ww = w3;
@@ -544,6 +568,10 @@ void free_all(r50_handle* h) {
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
         h->side[i] = nullptr; h->ev_join[i] = nullptr;
     }
+    if (h->ds_stream) (void)hipStreamDestroy(h->ds_stream);
+    if (h->ev_ds_fork) (void)hipEventDestroy(h->ev_ds_fork);
+    if (h->ev_ds_join) (void)hipEventDestroy(h->ev_ds_join);
+    h->ds_stream = nullptr; h->ev_ds_fork = nullptr; h->ev_ds_join = nullptr;
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     h->ev_fork = nullptr;
     for (auto& r : h->ev_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -716,6 +744,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "profile") h->profile = value ? 1 : 0;
     else if (k == "tile") h->tile_override = (int)value;
     else if (k == "fused_stem") h->fused_stem = value ? 1 : 0;
+    else if (k == "overlap_ds") h->overlap_ds = value ? 1 : 0;
     else if (k == "streams") { if (value < 1 || value > 4) return fail(h, R50_ERR_INVALID, "streams must be in [1,4]"); h->n_streams = (int)value; }
     else return fail(h, R50_ERR_INVALID, "r50_set_option: unknown key " + k);
     return R50_OK;
@@ -729,6 +758,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "tile") *value = h->tile_override;
     else if (k == "streams") *value = h->n_streams;
     else if (k == "fused_stem") *value = h->fused_stem;
+    else if (k == "overlap_ds") *value = h->overlap_ds;
     else if (k == "max_batch") *value = h->max_batch;
     else if (k == "workspace_bytes") *value = (int64_t)(5 * h->buf_bytes + (size_t)h->max_batch * STEM_HP * STEM_WP * 8);
     else return fail(h, R50_ERR_INVALID, "r50_get_option: unknown key " + k);

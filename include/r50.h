@@ -78,7 +78,10 @@ int r50_forward_layer(r50_handle* h, const float* x_nchw_f32_dev, int n, const c
                       void* stream);
 
 /* Options: "micro_batch" (frames per pass through the layer stack, 0 = whole batch),
- * "profile" (1 = bracket every kernel launch with HIP events, see r50_profile_*). */
+ * "profile" (1 = bracket every kernel launch with HIP events, see r50_profile_*),
+ * "streams" (1..4: split the batch over internal streams forked from / joined to the caller's; default 1),
+ * "overlap_ds" (1 = downsample convs on a side stream; default 0), "fused_stem" (default 1),
+ * "tile" (force an igemm tile id, 0 = tuned table). */
 int r50_set_option(r50_handle* h, const char* key, int64_t value);
 int r50_get_option(r50_handle* h, const char* key, int64_t* value);
 
