@@ -86,6 +86,8 @@ def main() -> None:
     ap.add_argument("--streams", type=int, default=0, help="internal streams the batch is split over (0 = library default)")
     ap.add_argument("--precision", choices=["bf16", "fp32x"], default="bf16",
                     help="bf16 = headline path; fp32x = fp32-class accuracy mode (bf16 head/tail pairs, 3 products per conv)")
+    ap.add_argument("--input", choices=["f32", "u8"], default="f32",
+                    help="f32 = the reference boundary (normalised fp32 NCHW frames); u8 = resized uint8 crops, normalised in the stem kernel")
     ap.add_argument("--no-fused-stem", action="store_true", help="A/B: run conv1 / maxpool as separate kernels")
     ap.add_argument("--no-overlap-ds", action="store_true", help="A/B: downsample convs on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,11 +129,16 @@ def main() -> None:
     if args.no_overlap_ds:
         bb.set_option("overlap_ds", 0)
     x = synthetic_frames(args.batch, seed=1234 + rank).to(dev)          # random data, resident in HBM
+    run = bb.features
+    if args.input == "u8":
+        g = torch.Generator().manual_seed(1234 + rank)
+        x = torch.randint(0, 256, (args.batch, 3, 224, 224), generator=g, dtype=torch.uint8).to(dev)
+        run = bb.features_u8
     feats = torch.empty((args.batch, 2048), dtype=torch.float32, device=dev)
     gathered = [torch.empty_like(feats) for _ in range(world)] if (dist is not None and rank == 0) else None
 
     def step():
-        bb.features(x, out=feats)
+        run(x, out=feats)
         if dist is not None:
             dist.gather(feats, gathered, dst=0)
 
@@ -163,7 +170,7 @@ def main() -> None:
         bb.set_option("profile", 1)
         bb.profile_reset()
         for _ in range(args.steps):
-            bb.features(x, out=feats)
+            run(x, out=feats)
         torch.cuda.synchronize(dev)
         prof = bb.profile_collect()
         bb.set_option("profile", 0)
@@ -186,9 +193,12 @@ def main() -> None:
                     "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
                     "flops_per_launch": ig["flops"] / max(1, ig["launches"]),
                     "layerwise_GBps": ig["bytes"] / (ig["ms"] * 1e-3) / 1e9 if ig["ms"] > 0 else 0.0}
-        tot_ms = sum(v["ms"] for v in prof.values())
-        kernels = {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["ms"] / args.steps,
-                       "share": v["ms"] / tot_ms if tot_ms else 0.0} for k, v in prof.items()}
+        classes = ("igemm", "conv1", "maxpool", "avgpool", "stem_pack")
+        tot_ms = sum(prof[k]["ms"] for k in classes)
+        kernels = {k: {"launches_per_step": prof[k]["launches"] / args.steps, "ms_per_step": prof[k]["ms"] / args.steps,
+                       "share": prof[k]["ms"] / tot_ms if tot_ms else 0.0} for k in classes if prof[k]["launches"]}
+        kernels["stages_ms_per_step"] = {f"layer{i}": sum(v["ms"] for n_, v in prof.items() if n_.startswith(f"layer{i}.")) / args.steps
+                                         for i in (1, 2, 3, 4)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -209,7 +219,7 @@ def main() -> None:
             "config": {"workload": f"ResNet-50[:-1] bf16 forward, batch {args.batch} x 224x224x3 fp32 NCHW frames per GPU "
                                    f"(BASELINE configs[1]), seeded synthetic weights, (N,2048) fp32 features"
                                    + (", RCCL gather to rank 0" if world > 1 else ""),
-                       "batch_per_gpu": args.batch, "micro_batch": args.micro_batch,
+                       "batch_per_gpu": args.batch, "micro_batch": args.micro_batch, "input": args.input,
                        "parallelism": f"frames sharded over {world} rank(s)"},
             "tflops": value * GFLOP_PER_FRAME / 1e3,
             "frac_of_mfma_peak_whole_step": value * GFLOP_PER_FRAME / 1e3 / MFMA_BF16_PEAK_TFLOPS / world,

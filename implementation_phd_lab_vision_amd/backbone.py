@@ -122,6 +122,27 @@ class ResNet50Backbone:
         _lib.check(lib.r50_forward(self._handle, x.data_ptr(), n, out.data_ptr(), stream), self._handle, "r50_forward")
         return out
 
+    def features_u8(self, x_u8: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(N,3,224,224) uint8 NCHW resized crops (what the reference holds before ``/255`` and ``Normalize``,
+        src/dataset.py:141-150,242-245) -> (N,2048) fp32.  Normalisation happens inside the stem kernel with the
+        reference's fp32 operations, so the result equals ``features(((x/255) - mean) / std)`` bit for bit."""
+        if self._handle is None:
+            raise _lib.R50Error("call .to('cuda:N') before running the backbone")
+        if x_u8.dim() != 4 or tuple(x_u8.shape[1:]) != (3, 224, 224) or x_u8.dtype != torch.uint8:
+            raise ValueError(f"expected uint8 (N,3,224,224) frames, got {x_u8.dtype} {tuple(x_u8.shape)}")
+        if x_u8.device != self._device:
+            raise ValueError(f"frames are on {x_u8.device}, backbone on {self._device}")
+        x_u8 = x_u8.contiguous()
+        n = x_u8.shape[0]
+        if out is None:
+            out = torch.empty((n, FEATURE_DIM), dtype=torch.float32, device=self._device)
+        if n == 0:
+            return out
+        lib = _lib.load_library()
+        stream = torch.cuda.current_stream(self._device).cuda_stream
+        _lib.check(lib.r50_forward_u8(self._handle, x_u8.data_ptr(), n, out.data_ptr(), stream), self._handle, "r50_forward_u8")
+        return out
+
     def layer(self, x: torch.Tensor, name: str) -> torch.Tensor:
         """Debug hook: named intermediate activation, NHWC (per-layer parity tests).  bf16 tensor in bf16
         mode; in fp32x mode the (head, tail) pair is recombined into an fp32 tensor."""

@@ -379,7 +379,22 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
 // ------------------------------------------------------------------------------------------------
 constexpr int STEM_HP = 230, STEM_WP = 232;
 
-__global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ x, u32x2* __restrict__ xp, int n_img) {
+// Frame element -> the fp32 value the reference's loader would hand to the backbone.
+//   float frames: already normalised (src/dataset.py:429).
+//   uint8 frames: the resized crop BEFORE `frames.to(float32) / 255.0` (src/dataset.py:148-149) and
+//   `Normalize(mean, std)` (:242-245) -- the same three fp32 operations, in the same order, so the result is
+//   bit-identical to the host path:  ((u8 / 255) - mean[c]) / std[c].
+__device__ __forceinline__ float frame_value(const float* p, int /*c*/) { return *p; }
+__device__ __forceinline__ float frame_value(const unsigned char* p, int c) {
+    const float mean = (c == 0) ? 0.485f : (c == 1) ? 0.456f : 0.406f;
+    const float stdv = (c == 0) ? 0.229f : (c == 1) ? 0.224f : 0.225f;
+    const float v = (float)(*p) / 255.0f;
+    return (v - mean) / stdv;
+}
+
+
+template <typename TIN>
+__global__ __launch_bounds__(256) void stem_pack_kernel(const TIN* __restrict__ x, u32x2* __restrict__ xp, int n_img) {
     const long long total = (long long)n_img * STEM_HP * STEM_WP;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -390,8 +405,8 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict_
         const int hi = hp - 3, wi = wp - 4;
         u32x2 o = (u32x2){0u, 0u};
         if ((unsigned)hi < 224u && (unsigned)wi < 224u) {
-            const float* p = x + ((size_t)n * 3 * 224 + hi) * 224 + wi;
-            const float c0 = p[0], c1 = p[224 * 224], c2 = p[2 * 224 * 224];
+            const TIN* p = x + ((size_t)n * 3 * 224 + hi) * 224 + wi;
+            const float c0 = frame_value(p, 0), c1 = frame_value(p + 224 * 224, 1), c2 = frame_value(p + 2 * 224 * 224, 2);
             o[0] = pack_bf16x2(c0, c1);
             o[1] = pack_bf16x2(c2, 0.f);
         }
@@ -563,7 +578,8 @@ constexpr int SF_IN_ROWS = 15;
 constexpr int SF_CONV_ROWS = 5;
 constexpr int SF_IN_BYTES = SF_IN_ROWS * STEM_ROW_BYTES;
 constexpr int SF_OUT_BYTES = SF_CONV_ROWS * 112 * 128;
-constexpr int SF_LDS_BYTES = STEM_W_BYTES + SF_IN_BYTES + SF_OUT_BYTES;
+constexpr int SF_TAB_BYTES = 3 * 256 * 4;               // uint8 frames: per-channel table u8 -> normalised fp32
+constexpr int SF_LDS_BYTES = STEM_W_BYTES + SF_IN_BYTES + SF_OUT_BYTES + SF_TAB_BYTES;
 constexpr int SF_THREADS = 512;                       // 8 waves: 5 of them run the MFMAs, all 8 pack and pool
 constexpr int SF_PACK_ROWS = 8;                       // rows per packing thread: threads [0,232) rows 0-7, [232,464) rows 8-14
 
@@ -572,15 +588,18 @@ __device__ __forceinline__ unsigned max_bf16x2_nonneg(unsigned a, unsigned b) { 
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
 
-__global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const float* __restrict__ x, const char* __restrict__ wpk,
+template <typename TIN>
+__global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const TIN* __restrict__ x, const char* __restrict__ wpk,
                                                                 const float* __restrict__ bias, __bf16* __restrict__ y,
-                                                                int n_tiles) {
+                                                                int n_tiles, const float* __restrict__ u8_table) {
     // Persistent: workgroup b handles tiles b, b + grid, ... (tile = image x pooled-row pair).  The fp32 pixels
     // of tile t+1 are loaded into registers while tile t runs its MFMAs and pooling; the weights are staged once.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_w = smem;
     char* s_in = smem + STEM_W_BYTES;
     char* s_out = smem + STEM_W_BYTES + SF_IN_BYTES;
+    float* s_tab = reinterpret_cast<float*>(smem + STEM_W_BYTES + SF_IN_BYTES + SF_OUT_BYTES);
+    constexpr bool U8 = (sizeof(TIN) == 1);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -588,6 +607,9 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const float* __r
 
     for (int c = tid; c < STEM_W_BYTES / 16; c += SF_THREADS)
         *reinterpret_cast<u32x4*>(s_w + c * 16) = *reinterpret_cast<const u32x4*>(wpk + c * 16);
+    if constexpr (U8) {                                 // 768 host-computed values ((u8/255) - mean[c]) / std[c]
+        for (int c = tid; c < 3 * 256; c += SF_THREADS) s_tab[c] = u8_table[c];
+    }
 
     // packing role: one padded column wp (wi = wp - 4) x 8 (or 7) consecutive input rows
     const int p_half = tid >= STEM_WP ? 1 : 0;
@@ -598,16 +620,26 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const float* __r
     auto load_tile = [&](int tile) {
         const int n = tile / 28;
         const int in0 = 4 * ((tile % 28) * 2) - 5 + p_half * SF_PACK_ROWS;    // first input row of this thread
-        const float* base = x + (size_t)n * 3 * 224 * 224 + (p_col_ok ? p_wp - 4 : 0);
+        const TIN* base = x + (size_t)n * 3 * 224 * 224 + (p_col_ok ? p_wp - 4 : 0);
 #pragma unroll
         for (int r = 0; r < SF_PACK_ROWS; ++r) {
             const int hi = in0 + r;
             const bool ok = p_col_ok && (unsigned)hi < 224u && (p_half * SF_PACK_ROWS + r) < SF_IN_ROWS;
-            const float* p = base + (ok ? hi * 224 : 0);
-            pc[r][0] = ok ? p[0] : 0.f;
-            pc[r][1] = ok ? p[224 * 224] : 0.f;
-            pc[r][2] = ok ? p[2 * 224 * 224] : 0.f;
+            const TIN* p = base + (ok ? hi * 224 : 0);
+            if constexpr (U8) {                        // raw bytes now (-1 = outside the image), table look-up at pack time
+                pc[r][0] = ok ? (float)p[0] : -1.f;
+                pc[r][1] = ok ? (float)p[224 * 224] : -1.f;
+                pc[r][2] = ok ? (float)p[2 * 224 * 224] : -1.f;
+            } else {
+                pc[r][0] = ok ? frame_value(p, 0) : 0.f;
+                pc[r][1] = ok ? frame_value(p + 224 * 224, 1) : 0.f;
+                pc[r][2] = ok ? frame_value(p + 2 * 224 * 224, 2) : 0.f;
+            }
         }
+    };
+    auto sample = [&](float v, int c) -> float {
+        if constexpr (U8) return v < 0.f ? 0.f : s_tab[c * 256 + (int)v];
+        else return v;
     };
 
     int tile = blockIdx.x;
@@ -622,7 +654,7 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const float* __r
                 const int row = p_half * SF_PACK_ROWS + r;
                 if (row < SF_IN_ROWS)
                     *reinterpret_cast<u32x2*>(s_in + (row * STEM_WP + p_wp) * 8) =
-                        (u32x2){pack_bf16x2(pc[r][0], pc[r][1]), pack_bf16x2(pc[r][2], 0.f)};
+                        (u32x2){pack_bf16x2(sample(pc[r][0], 0), sample(pc[r][1], 1)), pack_bf16x2(sample(pc[r][2], 2), 0.f)};
             }
         }
         __syncthreads();                               // s_in (and, first time, s_w) ready; previous pooling finished
@@ -719,7 +751,8 @@ __device__ __forceinline__ void split_bf16(float v, unsigned& head16, unsigned& 
     tail16 = pack_bf16x2(v - bf16_bits_to_f32(h), 0.f) & 0xffffu;
 }
 
-__global__ __launch_bounds__(256) void stem_pack_split_kernel(const float* __restrict__ x, u32x2* __restrict__ xp_head,
+template <typename TIN>
+__global__ __launch_bounds__(256) void stem_pack_split_kernel(const TIN* __restrict__ x, u32x2* __restrict__ xp_head,
                                                               u32x2* __restrict__ xp_tail, int n_img) {
     const long long total = (long long)n_img * STEM_HP * STEM_WP;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -731,11 +764,11 @@ __global__ __launch_bounds__(256) void stem_pack_split_kernel(const float* __res
         const int hi = hp - 3, wi = wp - 4;
         u32x2 oh = (u32x2){0u, 0u}, ot = (u32x2){0u, 0u};
         if ((unsigned)hi < 224u && (unsigned)wi < 224u) {
-            const float* p = x + ((size_t)n * 3 * 224 + hi) * 224 + wi;
+            const TIN* p = x + ((size_t)n * 3 * 224 + hi) * 224 + wi;
             unsigned h0, t0, h1, t1, h2, t2;
-            split_bf16(p[0], h0, t0);
-            split_bf16(p[224 * 224], h1, t1);
-            split_bf16(p[2 * 224 * 224], h2, t2);
+            split_bf16(frame_value(p, 0), h0, t0);
+            split_bf16(frame_value(p + 224 * 224, 1), h1, t1);
+            split_bf16(frame_value(p + 2 * 224 * 224, 2), h2, t2);
             oh[0] = h0 | (h1 << 16); oh[1] = h2;
             ot[0] = t0 | (t1 << 16); ot[1] = t2;
         }

@@ -59,6 +59,7 @@ struct r50_handle {
     std::vector<ConvLayer> convs;       // execution order, convs[0] = stem
     char* stem_w = nullptr;             // packed stem weights (device)
     char* stem_xp = nullptr;            // packed input image (device)
+    float* u8_table = nullptr;          // [3][256]: uint8 sample -> normalised fp32, for r50_forward_u8 (device)
     __bf16* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t buf_bytes = 0;
     Prof prof[PC_COUNT];
@@ -359,11 +360,12 @@ int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, 
     return R50_OK;
 }
 
-hipError_t launch_stem_pack(const float* x, void* xp, int n, hipStream_t s) {
+template <typename TIN>
+hipError_t launch_stem_pack(const TIN* x, void* xp, int n, hipStream_t s) {
     const long long total = (long long)n * STEM_HP * STEM_WP;
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
-    hipLaunchKernelGGL(stem_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (u32x2*)xp, n);
+    hipLaunchKernelGGL(stem_pack_kernel<TIN>, dim3((unsigned)blocks), dim3(256), 0, s, x, (u32x2*)xp, n);
     return hipGetLastError();
 }
 hipError_t launch_stem_conv(const void* xp, const void* wpk, const float* bias, void* y, int n, hipStream_t s) {
@@ -371,10 +373,12 @@ hipError_t launch_stem_conv(const void* xp, const void* wpk, const float* bias, 
                        (const char*)xp, (const char*)wpk, bias, (__bf16*)y);
     return hipGetLastError();
 }
-hipError_t launch_stem_fused(const float* x, const void* wpk, const float* bias, void* y, int n, hipStream_t s) {
+template <typename TIN>
+hipError_t launch_stem_fused(const TIN* x, const void* wpk, const float* bias, void* y, int n, hipStream_t s,
+                             const float* u8_table) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_kernel<TIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr = true;
@@ -387,15 +391,16 @@ hipError_t launch_stem_fused(const float* x, const void* wpk, const float* bias,
     }
     const int tiles = n * 28;
     const int grid = tiles < g_num_cus ? tiles : g_num_cus;       // 128 KB of LDS: one workgroup per CU
-    hipLaunchKernelGGL(stem_fused_kernel, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, tiles);
+    hipLaunchKernelGGL(stem_fused_kernel<TIN>, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, tiles, u8_table);
     return hipGetLastError();
 }
-hipError_t launch_stem_split(const float* x, char* xp_head, char* xp_tail, const char* w_head, const char* w_tail,
+template <typename TIN>
+hipError_t launch_stem_split(const TIN* x, char* xp_head, char* xp_tail, const char* w_head, const char* w_tail,
                              const float* bias, void* y, int n, hipStream_t s) {
     const long long total = (long long)n * STEM_HP * STEM_WP;
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
-    hipLaunchKernelGGL(stem_pack_split_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (u32x2*)xp_head, (u32x2*)xp_tail, n);
+    hipLaunchKernelGGL(stem_pack_split_kernel<TIN>, dim3((unsigned)blocks), dim3(256), 0, s, x, (u32x2*)xp_head, (u32x2*)xp_tail, n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -438,7 +443,8 @@ hipError_t launch_avgpool(const void* x, float* y, int n, int hw, int c, hipStre
 
 // Runs `n` frames (n <= max_batch) through the stack.  If `tap` is non-null, stops once the named
 // activation is available and reports it through tap_ptr / dims.
-int run_stack(r50_handle* h, const float* x, int n, float* out, hipStream_t s, const char* tap,
+template <typename TIN>
+int run_stack(r50_handle* h, const TIN* x, int n, float* out, hipStream_t s, const char* tap,
               const __bf16** tap_ptr, int64_t dims[4], int slot0 = 0) {
     // slot0: first frame slot of the workspace this call may use (concurrent calls on different streams
     // work on disjoint frame ranges of the same buffers)
@@ -465,7 +471,7 @@ int run_stack(r50_handle* h, const float* x, int n, float* out, hipStream_t s, c
     } else if (h->fused_stem && !(tap && std::string(tap) == "stem")) {
         // conv1 + bn1 + relu + maxpool in one kernel: frame in, (n,56,56,64) out
         prof_begin(h, s, r, PC_STEM_CONV, 2.0 * n * 112 * 112 * 64 * 147.0, (double)n * (3.0 * 224 * 224 * 4 + 56.0 * 56 * 64 * 2));
-        e = launch_stem_fused(x, h->stem_w, h->convs[0].bias, buf[1], n, s);
+        e = launch_stem_fused(x, h->stem_w, h->convs[0].bias, buf[1], n, s, h->u8_table);
         prof_end(h, s, r);
         if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem_fused: ") + hipGetErrorString(e));
         goto after_pool;
@@ -562,6 +568,7 @@ void free_all(r50_handle* h) {
     }
     if (h->stem_w) (void)hipFree(h->stem_w);
     if (h->stem_xp) (void)hipFree(h->stem_xp);
+    if (h->u8_table) (void)hipFree(h->u8_table);
     for (auto& b : h->buf) { if (b) (void)hipFree(b); b = nullptr; }
     for (int i = 0; i < 4; ++i) {
         if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
@@ -577,6 +584,47 @@ void free_all(r50_handle* h) {
     for (auto& r : h->ev_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& e : h->ev_free) (void)hipEventDestroy(e);
     h->ev_pending.clear(); h->ev_free.clear();
+}
+
+}  // namespace
+
+namespace {
+template <typename TIN>
+int forward_impl(r50_handle* h, const TIN* x, int n, float* out, void* stream) {
+    if (!h) return fail(nullptr, R50_ERR_INVALID, "r50_forward: null handle");
+    if (!h->loaded) return fail(h, R50_ERR_STATE, "r50_forward: weights not loaded");
+    if (!x || !out) return fail(h, R50_ERR_INVALID, "r50_forward: null buffer");
+    if (n < 0) return fail(h, R50_ERR_INVALID, "r50_forward: n < 0");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int chunk = h->max_batch;
+    if (h->micro_batch > 0 && h->micro_batch < chunk) chunk = h->micro_batch;
+    hipStream_t user = (hipStream_t)stream;
+    for (int i = 0; i < n; i += chunk) {
+        const int m = (n - i < chunk) ? (n - i) : chunk;
+        const int ns = (h->n_streams > 1 && m >= 2 * h->n_streams) ? h->n_streams : 1;
+        if (ns == 1) {
+            int rc = run_stack(h, x + (size_t)i * 3 * 224 * 224, m, out + (size_t)i * 2048, user, nullptr, nullptr, nullptr);
+            if (rc) return rc;
+            continue;
+        }
+        // fork: the side streams start after everything already queued on the caller's stream
+        if (!h->ev_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(h->ev_fork, user));
+        const int per = (m + ns - 1) / ns;
+        for (int k = 0; k < ns; ++k) {
+            const int f0 = k * per, cnt = (m - f0 < per) ? (m - f0) : per;
+            if (cnt <= 0) break;
+            if (!h->side[k]) HIP_TRY(h, hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+            if (!h->ev_join[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
+            HIP_TRY(h, hipStreamWaitEvent(h->side[k], h->ev_fork, 0));
+            int rc = run_stack(h, x + (size_t)(i + f0) * 3 * 224 * 224, cnt, out + (size_t)(i + f0) * 2048, h->side[k],
+                               nullptr, nullptr, nullptr, f0);
+            if (rc) return rc;
+            HIP_TRY(h, hipEventRecord(h->ev_join[k], h->side[k]));
+            HIP_TRY(h, hipStreamWaitEvent(user, h->ev_join[k], 0));    // join
+        }
+    }
+    return R50_OK;
 }
 
 }  // namespace
@@ -615,6 +663,18 @@ int r50_create(r50_handle** out, int device_id, int precision, int max_batch) {
     for (int i = 0; i < 5 && ok; ++i) ok = hipMalloc((void**)&h->buf[i], h->buf_bytes) == hipSuccess;
     ok = ok && hipMalloc((void**)&h->stem_xp, (size_t)max_batch * STEM_HP * STEM_WP * 8 * cmul) == hipSuccess;
     ok = ok && hipMalloc((void**)&h->stem_w, STEM_W_BYTES * cmul) == hipSuccess;
+    {   // the reference's host arithmetic, three fp32 operations per sample (src/dataset.py:148-149,242-245)
+        static const float kMean[3] = {0.485f, 0.456f, 0.406f}, kStd[3] = {0.229f, 0.224f, 0.225f};
+        std::vector<float> tab(3 * 256);
+        for (int c = 0; c < 3; ++c)
+            for (int v = 0; v < 256; ++v) {
+                const float a = (float)v / 255.0f;
+                const float b = a - kMean[c];
+                tab[c * 256 + v] = b / kStd[c];
+            }
+        ok = ok && hipMalloc((void**)&h->u8_table, tab.size() * sizeof(float)) == hipSuccess &&
+             hipMemcpy(h->u8_table, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (!ok) {
         free_all(h);
         delete h;
@@ -685,40 +745,11 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
 }
 
 int r50_forward(r50_handle* h, const float* x, int n, float* out, void* stream) {
-    if (!h) return fail(nullptr, R50_ERR_INVALID, "r50_forward: null handle");
-    if (!h->loaded) return fail(h, R50_ERR_STATE, "r50_forward: weights not loaded");
-    if (!x || !out) return fail(h, R50_ERR_INVALID, "r50_forward: null buffer");
-    if (n < 0) return fail(h, R50_ERR_INVALID, "r50_forward: n < 0");
-    HIP_TRY(h, hipSetDevice(h->device));
-    int chunk = h->max_batch;
-    if (h->micro_batch > 0 && h->micro_batch < chunk) chunk = h->micro_batch;
-    hipStream_t user = (hipStream_t)stream;
-    for (int i = 0; i < n; i += chunk) {
-        const int m = (n - i < chunk) ? (n - i) : chunk;
-        const int ns = (h->n_streams > 1 && m >= 2 * h->n_streams) ? h->n_streams : 1;
-        if (ns == 1) {
-            int rc = run_stack(h, x + (size_t)i * 3 * 224 * 224, m, out + (size_t)i * 2048, user, nullptr, nullptr, nullptr);
-            if (rc) return rc;
-            continue;
-        }
-        // fork: the side streams start after everything already queued on the caller's stream
-        if (!h->ev_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HIP_TRY(h, hipEventRecord(h->ev_fork, user));
-        const int per = (m + ns - 1) / ns;
-        for (int k = 0; k < ns; ++k) {
-            const int f0 = k * per, cnt = (m - f0 < per) ? (m - f0) : per;
-            if (cnt <= 0) break;
-            if (!h->side[k]) HIP_TRY(h, hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
-            if (!h->ev_join[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
-            HIP_TRY(h, hipStreamWaitEvent(h->side[k], h->ev_fork, 0));
-            int rc = run_stack(h, x + (size_t)(i + f0) * 3 * 224 * 224, cnt, out + (size_t)(i + f0) * 2048, h->side[k],
-                               nullptr, nullptr, nullptr, f0);
-            if (rc) return rc;
-            HIP_TRY(h, hipEventRecord(h->ev_join[k], h->side[k]));
-            HIP_TRY(h, hipStreamWaitEvent(user, h->ev_join[k], 0));    // join
-        }
-    }
-    return R50_OK;
+    return forward_impl<float>(h, x, n, out, stream);
+}
+
+int r50_forward_u8(r50_handle* h, const uint8_t* x, int n, float* out, void* stream) {
+    return forward_impl<unsigned char>(h, x, n, out, stream);
 }
 
 int r50_forward_layer(r50_handle* h, const float* x, int n, const char* layer, void* out, int64_t cap,
@@ -792,12 +823,12 @@ int r50_profile_collect(r50_handle* h) {
     return R50_OK;
 }
 
-int r50_profile_count(r50_handle* h) { return h ? PC_COUNT + (int)h->prof_layer.size() : 0; }
+int r50_profile_count(r50_handle* h) { return h ? PC_COUNT + (int)h->prof_layer.size() - 1 : 0; }
 
 int r50_profile_entry(r50_handle* h, int i, const char** name, int64_t* launches, double* total_ms, double* flops,
                       double* bytes) {
-    if (!h || i < 0 || i >= PC_COUNT + (int)h->prof_layer.size()) return R50_ERR_INVALID;
-    const Prof& p = (i < PC_COUNT) ? h->prof[i] : h->prof_layer[i - PC_COUNT];
+    if (!h || i < 0 || i >= PC_COUNT + (int)h->prof_layer.size() - 1) return R50_ERR_INVALID;
+    const Prof& p = (i < PC_COUNT) ? h->prof[i] : h->prof_layer[i - PC_COUNT + 1];    // [0] is the stem conv: class "conv1"
     if (name) *name = p.name;
     if (launches) *launches = p.launches;
     if (total_ms) *total_ms = p.ms;

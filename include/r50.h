@@ -69,6 +69,12 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
  * n may exceed max_batch: the call then loops over chunks of max_batch frames. */
 int r50_forward(r50_handle* h, const float* x_nchw_f32_dev, int n, float* out_f32_dev, void* stream);
 
+/* Same path, one step further upstream: frames as the resized uint8 crops the reference
+ * holds right before `frames.to(torch.float32) / 255.0` (src/dataset.py:141-150) and `Normalize(mean, std)`
+ * (:242-245), i.e. uint8 NCHW (n,3,224,224).  The three fp32 operations ((u8/255) - mean[c]) / std[c] are done
+ * in the stem kernel, bit-identical to the host path; the boundary moves 150,528 B per frame instead of 602,112. */
+int r50_forward_u8(r50_handle* h, const uint8_t* x_nchw_u8_dev, int n, float* out_f32_dev, void* stream);
+
 /* Debug hook for per-layer parity tests (no reference counterpart; equivalent to a forward hook
  * on the nn.Sequential).  Runs the network on x (n <= max_batch) and copies the named bf16 NHWC
  * activation into out_bf16_nhwc_dev.  Names: "stem", "pool", "layer{1..4}.{b}",

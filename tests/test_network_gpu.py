@@ -186,3 +186,21 @@ def test_fused_stem_equals_unfused(setup):
     finally:
         bb.set_option("fused_stem", 1)
     assert torch.equal(bb.features(xd), f0)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32x"])
+def test_uint8_frames_equal_host_normalised_frames(lib_built, precision):
+    """Boundary one step upstream: uint8 resized crops in, normalisation inside the stem kernel.
+    Must be bit-identical to feeding the host-normalised fp32 frames (dataset.py:148-149,242-245: /255, -mean, /std)."""
+    from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
+    g = torch.Generator().manual_seed(21)
+    u8 = torch.randint(0, 256, (5, 3, 224, 224), generator=g, dtype=torch.uint8)
+    u8[0] = 0
+    u8[1] = 255
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    x = (u8.to(torch.float32) / 255.0 - mean) / std                 # the reference's host path
+    bb = ResNet50Backbone(seed=0, max_batch=8, precision=precision).to("cuda:0").eval()
+    a = bb.features_u8(u8.to("cuda:0")).cpu()
+    b = bb.features(x.to("cuda:0")).cpu()
+    assert torch.isfinite(a).all() and torch.equal(a, b)
