@@ -122,11 +122,12 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
     static_assert(MR >= 2 && (MR % 2) == 0, "wave needs >= 32 couts");
     static_assert(NSTAGE == 2 || NSTAGE == 3, "2 or 3 LDS stages");
     constexpr int RPP = NT / 8;           // tile rows staged per pass (8 lanes x 16 B per 128-B row)
-    static_assert(BC % RPP == 0 && BP % RPP == 0, "tile rows must be a multiple of the staging pass");
+    static_assert(BC % RPP == 0 && BP % (16 * WP) == 0, "cout rows fill whole staging passes; pixels come in 16-blocks per wave");
     constexpr int WROWS = BC / RPP;       // staging rows per thread
-    constexpr int XROWS = BP / RPP;
+    constexpr int XROWS = (BP + RPP - 1) / RPP;   // the last pass may be partial (e.g. BP = 208): its rows read as zeros
+    constexpr int BP_PAD = XROWS * RPP;           // X rows held in LDS
     constexpr int PASS_BYTES = NT * 16;
-    constexpr int STAGE_BYTES = (BC + BP) * 128;
+    constexpr int STAGE_BYTES = (BC + BP_PAD) * 128;
     constexpr int LOADS_PER_STAGE = WROWS + XROWS;
     constexpr int D = NSTAGE - 1;
 
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
         for (int i = 0; i < XROWS; ++i) {
             const int m = p0 + i * RPP + srow;
             unsigned mask = 0u, voff = kOobOffset;
-            if (m < a.M) {
+            if ((BP_PAD == BP || i * RPP + srow < BP) && m < a.M) {
                 const int n = (int)fast_div((unsigned)m, a.div_howo);
                 const int r = m - n * a.HoWo;
                 const int ho = (int)fast_div((unsigned)r, a.div_wo);

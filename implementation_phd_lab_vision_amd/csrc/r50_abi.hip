@@ -205,6 +205,7 @@ FastDiv make_fast_div(unsigned d) {
 //   4 waves, 2 LDS stages:                1 = 128x128, 2 = 64x128, 3 = 64x256, 5 = 128x64
 //   8 waves, 3 LDS stages, counted vmcnt: 6 = 256x128, 7 = 128x256, 8 = 128x128
 //   8 waves, 2 LDS stages, 128 accumulator registers: 9 = 256x256 (wave 64c x 128p), 10 = 256x256 (wave 128c x 64p)
+//   8 waves, 2 LDS stages, pixel counts that divide M = 2^10 * 49: 11 = 256x208 (wave 32c x 208p), 12 = 256x224 (wave 64c x 112p)
 //   + 32: chip-sized persistent grid (tiles streamed through the LDS ring) instead of one tile per workgroup
 constexpr int kPersistBit = 32;
 int g_num_cus = 0;
@@ -214,7 +215,8 @@ hipError_t launch_igemm_t(ConvArgs a, bool persistent, hipStream_t s) {
     a.n_ctiles = a.Cout / BC;
     a.n_blocks = a.n_ctiles * ((a.M + BP - 1) / BP);
     a.div_ctiles = make_fast_div((unsigned)a.n_ctiles);
-    const size_t lds = (size_t)NSTAGE * (BC + BP) * 128;
+    constexpr int kRowsPerPass = WC * WP * 8;
+    const size_t lds = (size_t)NSTAGE * (BC + (BP + kRowsPerPass - 1) / kRowsPerPass * kRowsPerPass) * 128;
     auto kern = igemm_bf16_kernel<BC, BP, WC, WP, NSTAGE, SPLIT>;
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -249,11 +251,11 @@ hipError_t launch_igemm_t(ConvArgs a, bool persistent, hipStream_t s) {
 struct TunedTile { int h, cin, cout, ks, stride, res, tile; };
 constexpr TunedTile kTuned[] = {
     {56, 64, 64, 1, 1, 0, 34},    {56, 64, 64, 3, 1, 0, 2},     {56, 64, 256, 1, 1, 1, 39},   {56, 64, 256, 1, 1, 0, 38},
-    {56, 256, 64, 1, 1, 0, 2},    {56, 256, 128, 1, 1, 0, 40},  {56, 128, 128, 3, 2, 0, 33},  {28, 128, 512, 1, 1, 1, 39},
-    {56, 256, 512, 1, 2, 0, 42},  {28, 512, 128, 1, 1, 0, 33},  {28, 128, 128, 3, 1, 0, 37},  {28, 512, 256, 1, 1, 0, 38},
-    {28, 256, 256, 3, 2, 0, 41},  {14, 256, 1024, 1, 1, 1, 37}, {28, 512, 1024, 1, 2, 0, 41}, {14, 1024, 256, 1, 1, 0, 41},
-    {14, 256, 256, 3, 1, 0, 41},  {14, 1024, 512, 1, 1, 0, 41}, {14, 512, 512, 3, 2, 0, 33},  {7, 512, 2048, 1, 1, 1, 37},
-    {14, 1024, 2048, 1, 2, 0, 41}, {7, 2048, 512, 1, 1, 0, 33}, {7, 512, 512, 3, 1, 0, 33},
+    {56, 256, 64, 1, 1, 0, 2},    {56, 256, 128, 1, 1, 0, 40},  {56, 128, 128, 3, 2, 0, 1},   {28, 128, 512, 1, 1, 1, 39},
+    {56, 256, 512, 1, 2, 0, 42},  {28, 512, 128, 1, 1, 0, 1},   {28, 128, 128, 3, 1, 0, 33},  {28, 512, 256, 1, 1, 0, 43},
+    {28, 256, 256, 3, 2, 0, 44},  {14, 256, 1024, 1, 1, 1, 43}, {28, 512, 1024, 1, 2, 0, 43}, {14, 1024, 256, 1, 1, 0, 44},
+    {14, 256, 256, 3, 1, 0, 44},  {14, 1024, 512, 1, 1, 0, 43}, {14, 512, 512, 3, 2, 0, 33},  {7, 512, 2048, 1, 1, 1, 43},
+    {14, 1024, 2048, 1, 2, 0, 43}, {7, 2048, 512, 1, 1, 0, 33}, {7, 512, 512, 3, 1, 0, 33},
 };
 
 int auto_tile(const ConvArgs& a) {
@@ -284,6 +286,8 @@ hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s, bool split =
         case 8: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 128, 2, 4, 3>(a, pers, s);
         case 9: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 256, 4, 2, 2>(a, pers, s);
         case 10: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 256, 2, 4, 2>(a, pers, s);
+        case 11: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 208, 8, 1, 2>(a, pers, s);
+        case 12: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 224, 4, 2, 2>(a, pers, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -23,6 +23,8 @@ TILE_128x256_P3 = 7
 TILE_128x128_P3 = 8
 TILE_256x256 = 9         # 8 waves, 2 LDS stages, wave tile 64c x 128p
 TILE_256x256_B = 10      # 8 waves, 2 LDS stages, wave tile 128c x 64p
+TILE_256x208 = 11        # 8 waves, 2 LDS stages, wave tile 32c x 208p (208 = 13 x 16 fits M = 2^10 * 49)
+TILE_256x224 = 12        # 8 waves, 2 LDS stages, wave tile 64c x 112p
 PERSISTENT = 32          # + PERSISTENT: chip-sized grid, tiles streamed through the LDS ring
 
 

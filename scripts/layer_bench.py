@@ -8,7 +8,7 @@ from implementation_phd_lab_vision_amd.weights import conv_specs
 _lib.build_library(); _lib.load_library()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-TILES = [int(t) for t in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1, 2, 3, 5, 6, 7, 8, 9, 10, 33, 34, 35, 37, 38, 39, 40, 41, 42]
+TILES = [int(t) for t in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1, 2, 3, 5, 6, 7, 9, 10, 11, 12, 33, 34, 37, 38, 39, 40, 41, 42, 43, 44]
 d = torch.device('cuda:0')
 # distinct shapes in execution order with spatial size
 shapes = {}
@@ -39,7 +39,7 @@ for (hin, cin, cout, k, s, res), names in shapes.items():
     line = {}
     for tile in TILES:
         if (tile & 31) in (1, 5, 7, 8) and cout % 128: continue
-        if (tile & 31) in (6, 9, 10) and cout % 256: continue
+        if (tile & 31) in (6, 9, 10, 11, 12) and cout % 256: continue
         for _ in range(2):
             ops.conv2d_bf16(x, w, bias, stride=s, pad=pad, relu=True, residual=r, tile=tile)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)

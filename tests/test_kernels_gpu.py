@@ -59,7 +59,7 @@ def _tiles_for(cout):
     if cout % 128 == 0:
         t += [ops.TILE_128x128, ops.TILE_128x64, ops.TILE_128x256_P3, ops.TILE_128x128_P3]
     if cout % 256 == 0:
-        t += [ops.TILE_256x128_P3, ops.TILE_256x256, ops.TILE_256x256_B]
+        t += [ops.TILE_256x128_P3, ops.TILE_256x256, ops.TILE_256x256_B, ops.TILE_256x208, ops.TILE_256x224]
     return t + [x | ops.PERSISTENT for x in t if x != ops.TILE_AUTO]
 
 
