@@ -50,6 +50,8 @@ CONV_CASES = [
     (2, 7, 7, 2048, 512, 1, 1, 0, True, False),    # K = 2048
     (1, 56, 56, 64, 256, 1, 1, 0, True, True),     # layer1 conv3 at full spatial size
     (1, 1, 1, 64, 64, 3, 1, 1, True, False),       # single pixel: every tap but the centre is padding
+    (3, 5, 9, 128, 256, 3, 1, 1, True, True),      # non-square, 3 images: halo rows cross image borders
+    (2, 14, 14, 256, 256, 3, 1, 1, True, False),
 ]
 
 
