@@ -90,7 +90,22 @@ struct ConvArgs {
     int x_cstride;        // channels per pixel of the X tensor (Cin; 2*Cin in split mode: [hi | lo])
     int x_wrap;           // K chunk index at which the X chunk index wraps to 0 again (split: 2*Cin/64; else huge)
     int y_cstride;        // channels per pixel of Y / residual (Cout; 2*Cout in split mode)
+#if defined(R50_STAMP)    // diagnostic build (scripts/stamp_conv.py): per-wave cycle sums, 8 slots per wave
+    unsigned long long* dbg;
+#endif
 };
+
+// In-kernel cycle stamps of the role-specialised kernel (diagnostic build -DR50_STAMP=1 only).
+#if defined(R50_STAMP)
+#define R50_STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define R50_MARK(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long st_now = __builtin_readcyclecounter(); st_sum[i] += st_now - st_prev; st_prev = st_now; __builtin_amdgcn_sched_barrier(0); }
+#define R50_STAMP_FLUSH(nw) if (a.dbg && (threadIdx.x & 63) == 0) { _Pragma("unroll") for (int q = 0; q < 8; ++q) \
+        a.dbg[((size_t)blockIdx.x * (nw) + (threadIdx.x >> 6)) * 8 + q] = st_sum[q]; }
+#else
+#define R50_STAMP_DECL
+#define R50_MARK(i)
+#define R50_STAMP_FLUSH(nw)
+#endif
 
 __device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv d) {
     return d.mul == 0u ? n : (__umulhi(n, d.mul) >> d.shr);
@@ -197,14 +212,18 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
         char* sbase = smem + i_buf * STAGE_BYTES;
         // split mode: K per tap is [x_hi | x_lo | x_hi] against [w_hi | w_hi | w_lo]; the third block re-reads x_hi
         const int xcc = (i_cc >= a.x_wrap) ? i_cc - a.x_wrap : i_cc;
-        const int xofs = i_tapofs + xcc * 128;
+        // soffset has to be an SGPR: without the readfirstlane the compiler proves nothing about these
+        // loop-carried counters and wraps every X DMA in a waterfall loop (readfirstlane/cmp/saveexec/branch)
+        const int xofs = __builtin_amdgcn_readfirstlane(i_tapofs + xcc * 128);
+        const int wofs = __builtin_amdgcn_readfirstlane(i_wofs);
+        const int tap = __builtin_amdgcn_readfirstlane(i_tap);
 #pragma unroll
         for (int i = 0; i < WROWS; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (LDS_AS void*)(sbase + i * PASS_BYTES + wave * 1024), 16,
-                                                     w_voff[i], i_wofs, 0, 0);
+                                                     w_voff[i], wofs, 0, 0);
 #pragma unroll
         for (int i = 0; i < XROWS; ++i) {
-            const unsigned voff = ((x_mask[i] >> i_tap) & 1u) ? x_voff[i] : kOobOffset;
+            const unsigned voff = ((x_mask[i] >> tap) & 1u) ? x_voff[i] : kOobOffset;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void*)(sbase + BC * 128 + i * PASS_BYTES + wave * 1024),
                                                      16, voff, xofs, 0, 0);
         }
@@ -367,6 +386,302 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
             c_k = 0;
             c_tile += grid;
         }
+    }
+#else
+    (void)a;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Role-specialised implicit GEMM ("ws"): the same tile stream as igemm_bf16_kernel, but the LDS-DMA
+// instructions are issued by dedicated LOADER waves and the MFMAs by CONSUMER waves.
+// Why: in-kernel stamps on the unspecialised loop show a wave spending ~850 cycles per K-step just ISSUING
+// its 8 `buffer_load ... lds` (~100 cycles each: the wave is held while the address unit takes the 64 lanes)
+// next to ~800 cycles of fragment reads + 32 MFMAs (512 of them MFMA) -- the DMA latency itself is hidden.
+// A loader wave can sit in that issue stall for free; the consumer waves then run ds_read + MFMA only.
+// One workgroup per CU (NSTAGE stages of LDS), persistent over tiles.  Per stream step g:
+//     loaders:   issue DMAs of step g+D (D = NSTAGE-1) ; wait until their DMAs of step g+1 landed ; s_barrier
+//     consumers: [tile begin] ; ds_read + MFMA of step g ; [epilogue] ; s_barrier
+// RAW: the barrier ending step g comes after every loader's wait for stage g+1.
+// WAR: stage g+D goes into the buffer of stage g-1, which the consumers finished before the barrier ending
+//      step g-1.
+// ------------------------------------------------------------------------------------------------
+template <int BC, int BP, int CWC, int CWP, int NLOAD, int NSTAGE>
+__global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(const ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NCONS = CWC * CWP;
+    constexpr int MR = BC / CWC / 16;
+    constexpr int NR = BP / CWP / 16;
+    static_assert(MR >= 2 && (MR % 2) == 0, "consumer wave needs >= 32 couts");
+    static_assert(BP % (16 * CWP) == 0, "pixels come in 16-blocks per consumer wave");
+    constexpr int RPPL = NLOAD * 8;               // rows staged per loader pass
+    static_assert(BC % RPPL == 0, "cout rows fill whole loader passes");
+    constexpr int WROWS = BC / RPPL;
+    constexpr int XROWS = (BP + RPPL - 1) / RPPL;
+    constexpr int BP_PAD = XROWS * RPPL;
+    constexpr int PASS_BYTES = RPPL * 128;
+    constexpr int STAGE_BYTES = (BC + BP_PAD) * 128;
+    constexpr int LOADS_PER_STAGE = WROWS + XROWS;
+    constexpr int D = NSTAGE - 1;
+    static_assert(NSTAGE >= 3 && NSTAGE <= 4, "3 or 4 LDS stages");
+    constexpr bool BIG = (MR * NR > 16);
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = (wave >= NCONS);
+
+    const int grid = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, grid);
+    const int my_tiles = (a.n_blocks - first + grid - 1) / grid;
+    const int total = my_tiles * a.nk;
+
+    if (is_loader) {
+        // =============================== loader waves ===============================================
+        const int lw = wave - NCONS;
+        const int lt = tid - NCONS * 64;
+        const int srow = lt >> 3;
+        const int slot = lt & 7;
+        const int lchunk = slot ^ (srow & 7);
+        const __amdgpu_buffer_rsrc_t rsrc_w =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w), 0, a.w_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(a.x) - a.x_back), 0, a.x_records, 0x00020000);
+        unsigned x_voff[XROWS], x_mask[XROWS], w_voff[WROWS];
+        auto decode_tile = [&](int tile) {
+            const int pt = (int)fast_div((unsigned)tile, a.div_ctiles);
+            const int c0 = (tile - pt * a.n_ctiles) * BC, p0 = pt * BP;
+#pragma unroll
+            for (int i = 0; i < XROWS; ++i) {
+                const int m = p0 + i * RPPL + srow;
+                unsigned mask = 0u, voff = kOobOffset;
+                if ((BP_PAD == BP || i * RPPL + srow < BP) && m < a.M) {
+                    const int n = (int)fast_div((unsigned)m, a.div_howo);
+                    const int r = m - n * a.HoWo;
+                    const int ho = (int)fast_div((unsigned)r, a.div_wo);
+                    const int wo = r - ho * a.Wo;
+                    const int hc = ho * a.stride, wc = wo * a.stride;
+                    voff = (unsigned)(((n * a.H + hc) * a.W + wc) * a.x_cstride + lchunk * 8) * 2u;
+                    if (a.ks == 1) {
+                        mask = 1u;
+                    } else {
+                        const unsigned hm = (hc >= a.pad ? 1u : 0u) | 2u | (hc - a.pad + 2 < a.H ? 4u : 0u);
+                        const unsigned wm = (wc >= a.pad ? 1u : 0u) | 2u | (wc - a.pad + 2 < a.W ? 4u : 0u);
+                        mask = ((hm & 1u) ? wm : 0u) | ((hm & 2u) ? (wm << 3) : 0u) | ((hm & 4u) ? (wm << 6) : 0u);
+                    }
+                }
+                x_voff[i] = voff;
+                x_mask[i] = mask;
+            }
+#pragma unroll
+            for (int i = 0; i < WROWS; ++i) {
+                const int rho = i * RPPL + srow;
+                const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+                w_voff[i] = (unsigned)((c0 + cl) * a.Ktot + lchunk * 8) * 2u;
+            }
+        };
+        int i_tile = first, i_k = 0, i_tap = 0, i_cc = 0, i_dw = 0, i_wofs = 0, i_tapofs = 0, i_buf = 0;
+        const int row_adv = (a.W - a.ks) * a.x_cstride * 2;
+        decode_tile(i_tile);
+        auto stage_issue = [&]() {
+            char* sbase = smem + i_buf * STAGE_BYTES;
+            // soffset has to be an SGPR: without the readfirstlane the compiler wraps every DMA in a waterfall loop
+            const int xofs = __builtin_amdgcn_readfirstlane(i_tapofs + i_cc * 128);
+            const int wofs = __builtin_amdgcn_readfirstlane(i_wofs);
+            const int tap = __builtin_amdgcn_readfirstlane(i_tap);
+#pragma unroll
+            for (int i = 0; i < WROWS; ++i)
+#if defined(R50_ABLATE_OOB)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (LDS_AS void*)(sbase + i * PASS_BYTES + lw * 1024), 16,
+                                                         kOobOffset | (w_voff[i] & 0u), wofs, 0, 0);
+#else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (LDS_AS void*)(sbase + i * PASS_BYTES + lw * 1024), 16, w_voff[i],
+                                                         wofs, 0, 0);
+#endif
+#pragma unroll
+            for (int i = 0; i < XROWS; ++i) {
+#if defined(R50_ABLATE_OOB)      // diagnostic: every X DMA zero-fills (no L2 traffic for X)
+                const unsigned voff = kOobOffset | (x_mask[i] & 0u);
+#else
+                const unsigned voff = ((x_mask[i] >> tap) & 1u) ? x_voff[i] : kOobOffset;
+#endif
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void*)(sbase + BC * 128 + i * PASS_BYTES + lw * 1024), 16,
+                                                         voff, xofs, 0, 0);
+            }
+            i_buf = (i_buf == NSTAGE - 1) ? 0 : i_buf + 1;
+            i_wofs += 128;
+            if (++i_cc == a.cin_chunks) {
+                i_cc = 0;
+                ++i_tap;
+                i_tapofs += a.x_cstride * 2;
+                if (++i_dw == a.ks) { i_dw = 0; i_tapofs += row_adv; }
+            }
+            if (++i_k == a.nk) {
+                i_k = 0; i_tap = 0; i_cc = 0; i_dw = 0; i_wofs = 0; i_tapofs = 0;
+                i_tile += grid;
+                if (i_tile < a.n_blocks) decode_tile(i_tile);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+            if (s < total) stage_issue();
+        // stage 0 landed: at most D-1 younger stages may stay in flight
+        if (total >= D) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LOADS_PER_STAGE) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        R50_STAMP_DECL
+        for (int g = 0; g < total; ++g) {
+            if (g + D < total) stage_issue();
+            R50_MARK(0)                                  // DMA issue
+            // stages issued so far: 0 .. min(g+D, total-1); stage g+1 must be complete
+            if (g + D < total) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LOADS_PER_STAGE) : "memory");
+            } else if (D >= 3 && g + D - 1 < total) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D >= 3 ? D - 2 : 0) * LOADS_PER_STAGE) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            R50_MARK(1)                                  // wait: next stage landed
+            __builtin_amdgcn_s_barrier();
+            R50_MARK(2)                                  // barrier
+        }
+        R50_STAMP_FLUSH(NCONS + NLOAD)
+    } else {
+        // =============================== consumer waves =============================================
+        const int wave_c = wave / CWP, wave_p = wave % CWP;
+        const int fr = lane & 15, fq = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_r =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, a.res ? a.y_bytes : 0u, 0x00020000);
+        f32x4 acc[MR][NR];
+        constexpr bool PREFETCH_RES = !BIG;
+        u32x4 res_reg[PREFETCH_RES ? MR / 2 : 1][PREFETCH_RES ? NR : 1];
+        const bool has_res = (a.res != nullptr);
+        const int fphys0 = (fq ^ (fr & 7)) << 4;
+        const int w_frag = (wave_c * MR * 16 + fr) * 128;
+        const int x_frag = BC * 128 + (wave_p * NR * 16 + fr) * 128;
+        const int cout_lane = wave_c * MR * 16 + 8 * fq;
+        const int pix_lane = wave_p * NR * 16 + fr;
+        int c_tile = first, c_k = 0, c_buf = 0;
+        unsigned y_voff = 0u;
+        const unsigned y_rowstep = (unsigned)(16 * a.y_cstride * 2);
+
+        // The bias of the NEXT tile is fetched before the epilogue's stores go out: vmcnt retires in order, so a
+        // bias load issued behind 28 stores would wait for every one of them to be acknowledged.
+        f32x4 bias_reg[MR];
+        auto bias_fetch = [&](int tile) {
+            const int pt = (int)fast_div((unsigned)tile, a.div_ctiles);
+            const int c0 = (tile - pt * a.n_ctiles) * BC;
+#pragma unroll
+            for (int t = 0; t < MR / 2; ++t) {
+                bias_reg[2 * t] = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t);
+                bias_reg[2 * t + 1] = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t + 4);
+            }
+        };
+        auto tile_begin = [&]() {
+            const int pt = (int)fast_div((unsigned)c_tile, a.div_ctiles);
+            const int c0 = (c_tile - pt * a.n_ctiles) * BC, p0 = pt * BP;
+            y_voff = (unsigned)((p0 + pix_lane) * a.y_cstride + c0 + cout_lane) * 2u;
+#pragma unroll
+            for (int t = 0; t < MR / 2; ++t) {
+                const f32x4 b_lo = bias_reg[2 * t];
+                const f32x4 b_hi = bias_reg[2 * t + 1];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    acc[2 * t][j] = b_lo;
+                    acc[2 * t + 1][j] = b_hi;
+                    if constexpr (PREFETCH_RES) if (has_res)
+                        res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, 0);
+                }
+            }
+        };
+        // One consumer wave per SIMD has nobody to hide its LDS latency behind, so all fragment reads of the
+        // step go out first (both K halves): the second half lands under the first half's MFMAs.
+        auto compute = [&]() {
+            const char* sbase = smem + c_buf * STAGE_BYTES;
+            bf16x8 wf[2][MR], xf[2][NR];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int ph = fphys0 ^ (kk << 6);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) xf[kk][j] = *reinterpret_cast<const bf16x8*>(sbase + x_frag + j * 2048 + ph);
+#pragma unroll
+                for (int m = 0; m < MR; ++m) wf[kk][m] = *reinterpret_cast<const bf16x8*>(sbase + w_frag + m * 2048 + ph);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+#if defined(R50_ABLATE_MFMA)    // diagnostic: one MFMA per fragment pair column instead of MR*NR (keeps every LDS read live)
+                        { if (m == 0 || j == 0) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][m], xf[kk][j], acc[m][j], 0, 0, 0); }
+#else
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][m], xf[kk][j], acc[m][j], 0, 0, 0);
+#endif
+#if !defined(R50_ABLATE_MFMA)
+            if constexpr (NCONS + NLOAD <= 8) {     // 2 waves per SIMD: 256 registers, room for both halves' fragments
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MR + NR), 0);   // every LDS read of the step ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * MR * NR, 0);     // ... then the MFMAs
+            }
+#endif
+        };
+        auto epilogue = [&]() {
+#pragma unroll
+            for (int t = 0; t < MR / 2; ++t) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    f32x4 lo = acc[2 * t][j], hi = acc[2 * t + 1][j];
+                    const unsigned voff = y_voff + j * y_rowstep + 64 * t;
+                    if (has_res) {
+                        u32x4 r;
+                        if constexpr (PREFETCH_RES) r = res_reg[t][j];
+                        else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, 0, 0);
+                        lo[0] += bf16_bits_to_f32(r[0] & 0xffffu); lo[1] += __uint_as_float(r[0] & 0xffff0000u);
+                        lo[2] += bf16_bits_to_f32(r[1] & 0xffffu); lo[3] += __uint_as_float(r[1] & 0xffff0000u);
+                        hi[0] += bf16_bits_to_f32(r[2] & 0xffffu); hi[1] += __uint_as_float(r[2] & 0xffff0000u);
+                        hi[2] += bf16_bits_to_f32(r[3] & 0xffffu); hi[3] += __uint_as_float(r[3] & 0xffff0000u);
+                    }
+                    u32x4 out = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                                        pack_bf16x2(hi[2], hi[3])};
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) out[e] = relu_bf16x2(out[e]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, 0);
+                }
+            }
+        };
+        if (total > 0) bias_fetch(c_tile);
+        __builtin_amdgcn_s_barrier();                    // stage 0 landed
+        R50_STAMP_DECL
+        for (int g = 0; g < total; ++g) {
+            if (c_k == 0) tile_begin();
+            R50_MARK(0)                                  // tile begin
+            compute();
+#if defined(R50_STAMP)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 0" ::"v"(acc[MR - 1][NR - 1]) : "memory");   // the stamp waits for the last MFMA
+#endif
+            R50_MARK(1)                                  // fragment reads + MFMAs
+            c_buf = (c_buf == NSTAGE - 1) ? 0 : c_buf + 1;
+            if (++c_k == a.nk) {
+                const int next_tile = c_tile + grid;
+                if (next_tile < a.n_blocks) bias_fetch(next_tile);
+                epilogue();
+                c_k = 0;
+                c_tile = next_tile;
+            }
+            R50_MARK(2)                                  // epilogue
+            __builtin_amdgcn_s_barrier();
+            R50_MARK(3)                                  // barrier
+        }
+        R50_STAMP_FLUSH(NCONS + NLOAD)
     }
 #else
     (void)a;

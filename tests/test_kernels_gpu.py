@@ -62,7 +62,12 @@ def _tiles_for(cout):
         t += [ops.TILE_128x128, ops.TILE_128x64, ops.TILE_128x256_P3, ops.TILE_128x128_P3]
     if cout % 256 == 0:
         t += [ops.TILE_256x128_P3, ops.TILE_256x256, ops.TILE_256x256_B, ops.TILE_256x208, ops.TILE_256x224]
-    return t + [x | ops.PERSISTENT for x in t if x != ops.TILE_AUTO]
+    ws = [ops.WS | 9]
+    if cout % 128 == 0:
+        ws += [ops.WS | 1, ops.WS | 4, ops.WS | 8]
+    if cout % 256 == 0:
+        ws += [ops.WS | 3]
+    return t + [x | ops.PERSISTENT for x in t if x != ops.TILE_AUTO] + ws
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "n%d_%dx%d_c%d-%d_k%ds%dp%d_r%d_res%d" % tuple(int(v) for v in c))
