@@ -89,6 +89,7 @@ def main() -> None:
     ap.add_argument("--input", choices=["f32", "u8"], default="f32",
                     help="f32 = the reference boundary (normalised fp32 NCHW frames); u8 = resized uint8 crops, normalised in the stem kernel")
     ap.add_argument("--no-fused-stem", action="store_true", help="A/B: run conv1 / maxpool as separate kernels")
+    ap.add_argument("--no-fuse-tail", action="store_true", help="A/B: layer1 conv3 and the next conv1 as two igemm launches")
     ap.add_argument("--no-overlap-ds", action="store_true", help="A/B: downsample convs on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -126,6 +127,8 @@ def main() -> None:
         bb.set_option("streams", args.streams)
     if args.no_fused_stem:
         bb.set_option("fused_stem", 0)
+    if args.no_fuse_tail:
+        bb.set_option("fuse_tail", 0)
     if args.no_overlap_ds:
         bb.set_option("overlap_ds", 0)
     x = synthetic_frames(args.batch, seed=1234 + rank).to(dev)          # random data, resident in HBM
@@ -184,7 +187,7 @@ def main() -> None:
                 traffic = json.loads(tpath.read_text())["igemm"]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": "igemm_bf16_kernel (52 conv launches/step)", "achieved": achieved,
+        roofline = {"bound": "mfma", "kernel": "igemm_bf16_kernel + igemm_ws_kernel (%d conv launches/step)" % round(ig["launches"] / max(1, args.steps)), "achieved": achieved,
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
                     "traffic": traffic,
                     "traffic_note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch, batch 256, from "
@@ -193,7 +196,7 @@ def main() -> None:
                     "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
                     "flops_per_launch": ig["flops"] / max(1, ig["launches"]),
                     "layerwise_GBps": ig["bytes"] / (ig["ms"] * 1e-3) / 1e9 if ig["ms"] > 0 else 0.0}
-        classes = ("igemm", "conv1", "maxpool", "avgpool", "stem_pack")
+        classes = ("igemm", "bneck_tail", "conv1", "maxpool", "avgpool", "stem_pack")
         tot_ms = sum(prof[k]["ms"] for k in classes)
         kernels = {k: {"launches_per_step": prof[k]["launches"] / args.steps, "ms_per_step": prof[k]["ms"] / args.steps,
                        "share": prof[k]["ms"] / tot_ms if tot_ms else 0.0} for k in classes if prof[k]["launches"]}

@@ -689,6 +689,160 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// Bottleneck tail (layer1): conv3 1x1 (64 -> 256) + bn3 + identity + ReLU, and the NEXT block's
+// conv1 1x1 (256 -> C1) + bn1 + ReLU, in one pass over the pixels.
+// Why: at 56x56 these two layers are HBM-bound (the block output is 2*M*256 bytes, written by conv3 and read
+// straight back by the next conv1).  Fused, the block output is written once (the next block still needs it as
+// its identity) but never re-read: 1.44 KB/pixel -> 1.28 KB/pixel of HBM traffic for the pair ... and one
+// launch instead of two.
+// How: a wave owns 16 pixels and ALL 256 channels.  With the cout permutation of the igemm kernel the packed
+// bf16 result of conv3 in a lane -- channels 32t + 8*fq + 0..7 of pixel fr -- IS the B fragment of k-block t for
+// the second GEMM, so the block output goes from accumulators to the next MFMA without leaving registers.
+// Both weight matrices (32 KB + C1*512 B) stay in LDS for the whole launch; the activations never touch LDS
+// (conv2's output is loaded straight into B fragments).  Persistent: one 8-wave workgroup per CU, each wave
+// walks 16-pixel tiles and prefetches the next tile's inputs before it stores this tile's outputs (vmcnt
+// retires in order).
+// ------------------------------------------------------------------------------------------------
+struct TailArgs {
+    const __bf16* y2;     // (M, 64)   conv2 output
+    const __bf16* w3;     // (256, 64) folded conv3 weights, K contiguous
+    const float* b3;      // (256)
+    const __bf16* res;    // (M, 256)  identity
+    __bf16* out;          // (M, 256)  block output
+    const __bf16* w1;     // (C1, 256) folded weights of the next block's conv1
+    const float* b1;      // (C1)
+    __bf16* y1n;          // (M, C1)   next block's conv1 output
+    int M;
+};
+
+#ifndef TAIL_THREADS
+#define TAIL_THREADS 256
+#endif
+#ifndef TAIL_AUX
+#define TAIL_AUX 0
+#endif
+template <int C1>
+__global__ __launch_bounds__(TAIL_THREADS) void bneck_tail_kernel(const TailArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int W3_BYTES = 256 * 128;
+    constexpr int W1_BYTES = C1 * 512;
+    constexpr int B3_OFF = W3_BYTES + W1_BYTES;
+    constexpr int B1_OFF = B3_OFF + 256 * 4;
+    constexpr int M2 = C1 / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // weights -> LDS once.  LDS row rho holds channel perm(rho) (see igemm: 8 consecutive couts per lane)
+    for (int i = tid; i < 256 * 8; i += TAIL_THREADS) {
+        const int rho = i >> 3, c = i & 7;
+        const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+        *reinterpret_cast<u32x4*>(smem + rho * 128 + ((c ^ (rho & 7)) << 4)) =
+            *reinterpret_cast<const u32x4*>(a.w3 + cl * 64 + c * 8);
+    }
+    for (int i = tid; i < C1 * 32; i += TAIL_THREADS) {
+        const int rho = i >> 5, c = i & 31;
+        const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+        *reinterpret_cast<u32x4*>(smem + W3_BYTES + rho * 512 + ((c ^ (rho & 15)) << 4)) =
+            *reinterpret_cast<const u32x4*>(a.w1 + cl * 256 + c * 8);
+    }
+    for (int i = tid; i < 256; i += TAIL_THREADS) reinterpret_cast<float*>(smem + B3_OFF)[i] = a.b3[i];
+    for (int i = tid; i < C1; i += TAIL_THREADS) reinterpret_cast<float*>(smem + B1_OFF)[i] = a.b1[i];
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rs_y2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.y2), 0, (unsigned)a.M * 128u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.M * 512u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.M * 512u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.M * (C1 * 2u), 0x00020000);
+
+    const int ntiles = (a.M + 15) >> 4;
+    const int nwaves = gridDim.x * (TAIL_THREADS / 64);
+    const int w3_frag = fr * 128, fphys0 = (fq ^ (fr & 7)) << 4;
+    const int w1_frag = W3_BYTES + fr * 512;
+
+    // Inputs of a tile live in ONE register set: as soon as a register has been consumed, the load of the next
+    // tile's value is issued into it (a tile takes far longer than a memory round trip, so the in-order vmcnt
+    // behind this tile's stores never stalls).
+    u32x4 xf[2], rs[8];
+    int tile = blockIdx.x * (TAIL_THREADS / 64) + wave;
+    {
+        const unsigned pix = (unsigned)(tile * 16 + fr);           // past M: the descriptor returns zeros
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) xf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_y2, pix * 128u + kk * 64 + fq * 16, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix * 512u + t * 64 + fq * 16, 0, TAIL_AUX);
+    }
+    for (; tile < ntiles; tile += nwaves) {
+        const unsigned pix = (unsigned)(tile * 16 + fr);
+        const unsigned pix_n = (unsigned)((tile + nwaves) * 16 + fr);
+        const bf16x8 xb0 = __builtin_bit_cast(bf16x8, xf[0]), xb1 = __builtin_bit_cast(bf16x8, xf[1]);
+        // The weights in LDS never change, so the compiler would hoist all 64+ fragment reads out of the tile
+        // loop and spill them; an opaque zero per iteration keeps the reads where they are used.
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));
+        const char* lds = smem + opaque;
+        // ---- conv3 (256 x 64) x (64 x 16 pixels), 32 couts at a time, + identity, ReLU, bf16: the block output
+        //      and at the same time the B fragment of k-block t of the second GEMM
+        u32x4 outp[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            f32x4 lo = *reinterpret_cast<const f32x4*>(lds + B3_OFF + (32 * t + 8 * fq) * 4);
+            f32x4 hi = *reinterpret_cast<const f32x4*>(lds + B3_OFF + (32 * t + 8 * fq + 4) * 4);
+            const char* wrow = lds + w3_frag + (2 * t) * 2048;
+            lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + fphys0), xb0, lo, 0, 0, 0);
+            hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + 2048 + fphys0), xb0, hi, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + (fphys0 ^ 64)), xb1, lo, 0, 0, 0);
+            hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + 2048 + (fphys0 ^ 64)), xb1, hi, 0, 0, 0);
+            const u32x4 r = rs[t];
+            lo[0] += bf16_bits_to_f32(r[0] & 0xffffu); lo[1] += __uint_as_float(r[0] & 0xffff0000u);
+            lo[2] += bf16_bits_to_f32(r[1] & 0xffffu); lo[3] += __uint_as_float(r[1] & 0xffff0000u);
+            hi[0] += bf16_bits_to_f32(r[2] & 0xffffu); hi[1] += __uint_as_float(r[2] & 0xffff0000u);
+            hi[2] += bf16_bits_to_f32(r[3] & 0xffffu); hi[3] += __uint_as_float(r[3] & 0xffff0000u);
+            u32x4 o = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                              pack_bf16x2(hi[2], hi[3])};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+            outp[t] = o;
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, pix * 512u + t * 64 + fq * 16, 0, TAIL_AUX);
+            rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix_n * 512u + t * 64 + fq * 16, 0, TAIL_AUX);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) xf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_y2, pix_n * 128u + kk * 64 + fq * 16, 0, 0);
+        // ---- next conv1: (C1 x 256) x (256 x 16 pixels), K blocks straight from outp
+        f32x4 acc2[M2];
+#pragma unroll
+        for (int t2 = 0; t2 < M2 / 2; ++t2) {
+            acc2[2 * t2] = *reinterpret_cast<const f32x4*>(lds + B1_OFF + (32 * t2 + 8 * fq) * 4);
+            acc2[2 * t2 + 1] = *reinterpret_cast<const f32x4*>(lds + B1_OFF + (32 * t2 + 8 * fq + 4) * 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const bf16x8 kb = __builtin_bit_cast(bf16x8, outp[t]);
+#pragma unroll
+            for (int m2 = 0; m2 < M2; ++m2) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds + w1_frag + m2 * 8192 + (((4 * t + fq) ^ fr) << 4));
+                acc2[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, kb, acc2[m2], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < M2 / 2; ++t2) {
+            const f32x4 lo = acc2[2 * t2], hi = acc2[2 * t2 + 1];
+            u32x4 o = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                              pack_bf16x2(hi[2], hi[3])};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, pix * (C1 * 2u) + t2 * 64 + fq * 16, 0, 0);
+        }
+    }
+#else
+    (void)a;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stem, step 1: fp32 NCHW (N,3,224,224) -> bf16 "NHWC4" with a zero border:
 //   xp[n][hp][wp][4], hp = hi + 3 in [0,230), wp = wi + 4 in [0,232); channel 3 = 0.
 // One thread per output pixel (8 B).  The border is rewritten every call.

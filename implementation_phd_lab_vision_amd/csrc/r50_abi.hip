@@ -21,8 +21,8 @@ struct Prof {
     int64_t launches = 0;
     double ms = 0, flops = 0, bytes = 0;
 };
-enum ProfClass { PC_IGEMM = 0, PC_STEM_CONV, PC_MAXPOOL, PC_AVGPOOL, PC_STEM_PACK, PC_COUNT };
-const char* kProfNames[PC_COUNT] = {"igemm", "conv1", "maxpool", "avgpool", "stem_pack"};
+enum ProfClass { PC_IGEMM = 0, PC_STEM_CONV, PC_MAXPOOL, PC_AVGPOOL, PC_STEM_PACK, PC_TAIL, PC_COUNT };
+const char* kProfNames[PC_COUNT] = {"igemm", "conv1", "maxpool", "avgpool", "stem_pack", "bneck_tail"};
 
 struct EvRec {
     hipEvent_t a, b;
@@ -51,6 +51,7 @@ struct r50_handle {
     hipStream_t ds_stream = nullptr;
     hipEvent_t ev_ds_fork = nullptr, ev_ds_join = nullptr;
     int fused_stem = 1;                 // bf16 mode: conv1+bn1+relu+maxpool in one kernel
+    int fuse_tail = 1;                  // bf16 mode, layer1: conv3 + identity + ReLU + the next block's conv1 in one kernel
     int n_streams = 1;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -385,6 +386,39 @@ void prof_end(r50_handle* h, hipStream_t s, EvRec& r) {
     h->ev_pending.push_back(r);
 }
 
+// conv3 (64 -> 256) + identity + ReLU + next conv1 (256 -> c1) in one launch (kernels.h: bneck_tail_kernel)
+hipError_t launch_bneck_tail(const void* y2, long long m, const void* w3, const float* b3, const void* res, void* out,
+                             const void* w1, int c1, const float* b1, void* y1n, hipStream_t s) {
+    if (!y2 || !w3 || !b3 || !res || !out || !w1 || !b1 || !y1n || m <= 0 || m * 512 >= (1ll << 31)) return hipErrorInvalidValue;
+    if (c1 != 64 && c1 != 128) return hipErrorInvalidValue;
+    TailArgs a;
+    a.y2 = (const __bf16*)y2; a.w3 = (const __bf16*)w3; a.b3 = b3; a.res = (const __bf16*)res; a.out = (__bf16*)out;
+    a.w1 = (const __bf16*)w1; a.b1 = b1; a.y1n = (__bf16*)y1n; a.M = (int)m;
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        g_num_cus = prop.multiProcessorCount;
+    }
+    const long long tiles = (m + 15) / 16;
+    #ifndef TAIL_GRID_MULT
+#define TAIL_GRID_MULT 1
+#endif
+    const int grid = (int)std::min<long long>((tiles + TAIL_THREADS / 64 - 1) / (TAIL_THREADS / 64), (long long)g_num_cus * TAIL_GRID_MULT);
+    const size_t lds = 256 * 128 + (size_t)c1 * 512 + 256 * 4 + (size_t)c1 * 4;
+    hipError_t e;
+    if (c1 == 64) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_tail_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bneck_tail_kernel<64>, dim3(grid), dim3(TAIL_THREADS), lds, s, a);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_tail_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bneck_tail_kernel<128>, dim3(grid), dim3(TAIL_THREADS), lds, s, a);
+    }
+    return hipGetLastError();
+}
+
 int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, int ww, const __bf16* res,
              __bf16* y, int relu, hipStream_t s, int* ho, int* wo) {
     ConvArgs a;
@@ -539,13 +573,17 @@ after_pool:
     if (hit("pool", buf[1], 56, 56, 64)) return R50_OK;
 
     int cur = 1, hh = 56, ww = 56;
+    int pre_t1 = -1;            // buffer that already holds the coming block's conv1 output (fused tail), or -1
     size_t li = 1;
     for (int si = 0; si < 4; ++si) {
         const int blocks = kStages[si][1];
         for (int b = 0; b < blocks; ++b) {
             int fr[4], nf = 0;
+            if (pre_t1 >= 0) fr[nf++] = pre_t1;          // conv1 of this block was computed by the previous block's fused tail
             for (int i = 0; i < 5; ++i)
-                if (i != cur) fr[nf++] = i;
+                if (i != cur && i != pre_t1) fr[nf++] = i;
+            const bool have_t1 = (pre_t1 >= 0);
+            pre_t1 = -1;
             const std::string p = "layer" + std::to_string(si + 1) + "." + std::to_string(b);
             const ConvLayer& c1 = h->convs[li];
             const ConvLayer& c2 = h->convs[li + 1];
@@ -572,8 +610,12 @@ after_pool:
                 HIP_TRY(h, hipEventRecord(h->ev_ds_join, sd));
                 idn = buf[fr[2]];
             }
-            rc = run_conv(h, c1, buf[cur], n, hh, ww, nullptr, buf[fr[0]], 1, s, &h1, &w1);
-            if (rc) return rc;
+            if (have_t1) {
+                h1 = hh; w1 = ww;
+            } else {
+                rc = run_conv(h, c1, buf[cur], n, hh, ww, nullptr, buf[fr[0]], 1, s, &h1, &w1);
+                if (rc) return rc;
+            }
             if (hit(p + ".t1", buf[fr[0]], h1, w1, c1.cout)) return R50_OK;
             rc = run_conv(h, c2, buf[fr[0]], n, h1, w1, nullptr, buf[fr[1]], 1, s, &h2, &w2);
             if (rc) return rc;
@@ -587,8 +629,26 @@ after_pool:
                 idn = buf[fr[2]];
             }
             if (ds_side) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_ds_join, 0));   // conv3 needs the downsample output
-            rc = run_conv(h, c3, buf[fr[1]], n, h2, w2, idn, buf[fr[3]], 1, s, &h3, &w3);
-            if (rc) return rc;
+            // layer1: conv3 + identity + ReLU and the next block's conv1 share one pass over the pixels
+            const size_t li_next = li + ((b == 0) ? 4 : 3);
+            const ConvLayer* nx = (li_next < h->convs.size()) ? &h->convs[li_next] : nullptr;
+            const bool fuse = !split && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
+                              c3.cin == 64 && c3.cout == 256 && nx->ks == 1 && nx->stride == 1 && nx->cin == 256 &&
+                              (nx->cout == 64 || nx->cout == 128);
+            if (fuse) {
+                const long long m = (long long)n * h2 * w2;
+                EvRec rt{};
+                prof_begin(h, s, rt, PC_TAIL, 2.0 * m * (256.0 * 64 + (double)nx->cout * 256),
+                           2.0 * (m * (64.0 + 256 + 256 + nx->cout) + 256.0 * 64 + 256.0 * nx->cout), (int)(&c3 - &h->convs[0]));
+                e = launch_bneck_tail(buf[fr[1]], m, c3.w, c3.bias, idn, buf[fr[3]], nx->w, nx->cout, nx->bias, buf[fr[0]], s);
+                prof_end(h, s, rt);
+                if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_tail launch (" + c3.conv_key + "): " + hipGetErrorString(e));
+                h3 = h2; w3 = w2;
+                pre_t1 = fr[0];
+            } else {
+                rc = run_conv(h, c3, buf[fr[1]], n, h2, w2, idn, buf[fr[3]], 1, s, &h3, &w3);
+                if (rc) return rc;
+            }
             cur = fr[3]; hh = h3; ww = w3;
             if (hit(p, buf[cur], hh, ww, c3.cout)) return R50_OK;
             li += (b == 0) ? 4 : 3;
@@ -817,6 +877,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "profile") h->profile = value ? 1 : 0;
     else if (k == "tile") h->tile_override = (int)value;
     else if (k == "fused_stem") h->fused_stem = value ? 1 : 0;
+    else if (k == "fuse_tail") h->fuse_tail = value ? 1 : 0;
     else if (k == "overlap_ds") h->overlap_ds = value ? 1 : 0;
     else if (k == "streams") { if (value < 1 || value > 4) return fail(h, R50_ERR_INVALID, "streams must be in [1,4]"); h->n_streams = (int)value; }
     else return fail(h, R50_ERR_INVALID, "r50_set_option: unknown key " + k);
@@ -831,6 +892,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "tile") *value = h->tile_override;
     else if (k == "streams") *value = h->n_streams;
     else if (k == "fused_stem") *value = h->fused_stem;
+    else if (k == "fuse_tail") *value = h->fuse_tail;
     else if (k == "overlap_ds") *value = h->overlap_ds;
     else if (k == "max_batch") *value = h->max_batch;
     else if (k == "workspace_bytes") *value = (int64_t)(5 * h->buf_bytes + (size_t)h->max_batch * STEM_HP * STEM_WP * 8);
@@ -916,6 +978,14 @@ int r50_op_conv2d(const void* x, int n, int h, int w, int cin, const void* wt, c
 #endif
     hipError_t e = launch_igemm(a, tile, (hipStream_t)stream);
     if (e != hipSuccess) return fail(nullptr, R50_ERR_HIP, std::string("r50_op_conv2d: ") + hipGetErrorString(e));
+    return R50_OK;
+}
+
+int r50_op_bneck_tail(const void* y2, int64_t m, const void* w3, const float* b3, const void* res, void* out, const void* w1,
+                      int c1, const float* b1, void* y1n, void* stream) {
+    hipError_t e = launch_bneck_tail(y2, m, w3, b3, res, out, w1, c1, b1, y1n, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
+                                     std::string("r50_op_bneck_tail: ") + hipGetErrorString(e));
     return R50_OK;
 }
 

@@ -87,7 +87,8 @@ int r50_forward_layer(r50_handle* h, const float* x_nchw_f32_dev, int n, const c
  * "profile" (1 = bracket every kernel launch with HIP events, see r50_profile_*),
  * "streams" (1..4: split the batch over internal streams forked from / joined to the caller's; default 1),
  * "overlap_ds" (1 = downsample convs on a side stream; default 0), "fused_stem" (default 1),
- * "tile" (force an igemm tile id, 0 = tuned table). */
+ * "fuse_tail" (layer1: conv3 + identity + ReLU + the next block's conv1 in one kernel; default 1),
+ * "tile" (force an igemm tile id for every conv, 0 = tuned table; also turns "fuse_tail" off). */
 int r50_set_option(r50_handle* h, const char* key, int64_t value);
 int r50_get_option(r50_handle* h, const char* key, int64_t* value);
 
@@ -131,6 +132,15 @@ int r50_op_stem(const float* x_nchw_f32_dev, int n, const float* w_oihw_f32_host
 
 /* MaxPool2d(3, stride 2, pad 1) on bf16 NHWC; c % 8 == 0. */
 int r50_op_maxpool(const void* x_nhwc_bf16, int n, int h, int w, int c, void* y_nhwc_bf16, void* stream);
+
+/* Bottleneck tail of layer1 in one launch: conv3 1x1 (64 -> 256) + bn3 + identity + ReLU -> out (m,256), and the
+ * next block's conv1 1x1 (256 -> c1, c1 in {64,128}) + bn1 + ReLU -> y1n (m,c1).  Replaces, for two consecutive
+ * torchvision Bottleneck blocks, `out = relu(bn3(conv3(out)) + identity)` of the first and
+ * `out = relu(bn1(conv1(x)))` of the second (upstream torchvision models/resnet.py Bottleneck.forward; the
+ * reference builds them at src/preprocess_resnet_features.py:207).  All tensors bf16 NHWC with m = n*h*w pixels,
+ * weights folded (cout, cin) K-contiguous, biases fp32. */
+int r50_op_bneck_tail(const void* y2_bf16, int64_t m, const void* w3_bf16, const float* b3, const void* identity_bf16,
+                      void* out_bf16, const void* w1_bf16, int c1, const float* b1, void* y1n_bf16, void* stream);
 
 /* AdaptiveAvgPool2d((1,1)) + flatten(1): (n,hw,c) bf16 -> (n,c) fp32; c % 8 == 0. */
 int r50_op_avgpool(const void* x_nhwc_bf16, int n, int hw, int c, float* y_f32, void* stream);

@@ -188,6 +188,24 @@ def test_fused_stem_equals_unfused(setup):
     assert torch.equal(bb.features(xd), f0)
 
 
+def test_fused_bottleneck_tail_equals_unfused(setup):
+    """layer1: conv3 + identity + ReLU + the next block's conv1 in one kernel must give, bit for bit, what the two
+    igemm launches give -- at every tap the fusion touches and at the final features."""
+    bb, x, *_ = setup
+    xd = x.to("cuda:0")
+    assert bb.get_option("fuse_tail") == 1
+    names = ["layer1.0", "layer1.1.t1", "layer1.1", "layer1.2.t1", "layer1.2", "layer2.0.t1", "layer2.0.ds", "layer2.0"]
+    fused = {k: bb.layer(xd, k).clone() for k in names}
+    f1 = bb.features(xd).clone()
+    bb.set_option("fuse_tail", 0)
+    try:
+        for k in names:
+            assert torch.equal(bb.layer(xd, k), fused[k]), k
+        assert torch.equal(bb.features(xd), f1)
+    finally:
+        bb.set_option("fuse_tail", 1)
+
+
 @pytest.mark.parametrize("precision", ["bf16", "fp32x"])
 def test_uint8_frames_equal_host_normalised_frames(lib_built, precision):
     """Boundary one step upstream: uint8 resized crops in, normalisation inside the stem kernel.
