@@ -707,7 +707,9 @@ struct TailArgs {
     const __bf16* y2;     // (M, 64)   conv2 output
     const __bf16* w3;     // (256, 64) folded conv3 weights, K contiguous
     const float* b3;      // (256)
-    const __bf16* res;    // (M, 256)  identity
+    const __bf16* res;    // (M, 256)  identity; with DS: (M, 64) the block INPUT, the identity is bf16(wd . input + bd)
+    const __bf16* wd;     // DS only: (256, 64) folded downsample weights
+    const float* bd;      // DS only: (256)
     __bf16* out;          // (M, 256)  block output
     const __bf16* w1;     // (C1, 256) folded weights of the next block's conv1
     const float* b1;      // (C1)
@@ -721,13 +723,15 @@ struct TailArgs {
 #ifndef TAIL_AUX
 #define TAIL_AUX 0
 #endif
-template <int C1>
+template <int C1, bool DS>
 __global__ __launch_bounds__(TAIL_THREADS) void bneck_tail_kernel(const TailArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int W3_BYTES = 256 * 128;
     constexpr int W1_BYTES = C1 * 512;
-    constexpr int B3_OFF = W3_BYTES + W1_BYTES;
+    constexpr int WD_OFF = W3_BYTES + W1_BYTES;                 // DS: downsample weights, same image as w3
+    constexpr int B3_OFF = WD_OFF + (DS ? W3_BYTES : 0);
     constexpr int B1_OFF = B3_OFF + 256 * 4;
+    constexpr int BD_OFF = B1_OFF + C1 * 4;
     constexpr int M2 = C1 / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -747,6 +751,15 @@ __global__ __launch_bounds__(TAIL_THREADS) void bneck_tail_kernel(const TailArgs
         *reinterpret_cast<u32x4*>(smem + W3_BYTES + rho * 512 + ((c ^ (rho & 15)) << 4)) =
             *reinterpret_cast<const u32x4*>(a.w1 + cl * 256 + c * 8);
     }
+    if constexpr (DS) {
+        for (int i = tid; i < 256 * 8; i += TAIL_THREADS) {
+            const int rho = i >> 3, c = i & 7;
+            const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+            *reinterpret_cast<u32x4*>(smem + WD_OFF + rho * 128 + ((c ^ (rho & 7)) << 4)) =
+                *reinterpret_cast<const u32x4*>(a.wd + cl * 64 + c * 8);
+        }
+        for (int i = tid; i < 256; i += TAIL_THREADS) reinterpret_cast<float*>(smem + BD_OFF)[i] = a.bd[i];
+    }
     for (int i = tid; i < 256; i += TAIL_THREADS) reinterpret_cast<float*>(smem + B3_OFF)[i] = a.b3[i];
     for (int i = tid; i < C1; i += TAIL_THREADS) reinterpret_cast<float*>(smem + B1_OFF)[i] = a.b1[i];
     __syncthreads();
@@ -754,7 +767,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void bneck_tail_kernel(const TailArgs
     const __amdgpu_buffer_rsrc_t rs_y2 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.y2), 0, (unsigned)a.M * 128u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.M * 512u, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.M * (DS ? 128u : 512u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.M * 512u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.M * (C1 * 2u), 0x00020000);
 
@@ -766,14 +779,20 @@ __global__ __launch_bounds__(TAIL_THREADS) void bneck_tail_kernel(const TailArgs
     // Inputs of a tile live in ONE register set: as soon as a register has been consumed, the load of the next
     // tile's value is issued into it (a tile takes far longer than a memory round trip, so the in-order vmcnt
     // behind this tile's stores never stalls).
-    u32x4 xf[2], rs[8];
+    constexpr int NRS = DS ? 2 : 8;      // identity registers: 8 chunks of the identity itself, or 2 B fragments of the block input
+    u32x4 xf[2], rs[NRS];
     int tile = blockIdx.x * (TAIL_THREADS / 64) + wave;
     {
         const unsigned pix = (unsigned)(tile * 16 + fr);           // past M: the descriptor returns zeros
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) xf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_y2, pix * 128u + kk * 64 + fq * 16, 0, 0);
+        if constexpr (DS) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix * 512u + t * 64 + fq * 16, 0, TAIL_AUX);
+            for (int kk = 0; kk < 2; ++kk) rs[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix * 128u + kk * 64 + fq * 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix * 512u + t * 64 + fq * 16, 0, TAIL_AUX);
+        }
     }
     for (; tile < ntiles; tile += nwaves) {
         const unsigned pix = (unsigned)(tile * 16 + fr);
@@ -796,7 +815,22 @@ __global__ __launch_bounds__(TAIL_THREADS) void bneck_tail_kernel(const TailArgs
             hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + 2048 + fphys0), xb0, hi, 0, 0, 0);
             lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + (fphys0 ^ 64)), xb1, lo, 0, 0, 0);
             hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + 2048 + (fphys0 ^ 64)), xb1, hi, 0, 0, 0);
-            const u32x4 r = rs[t];
+            u32x4 r;
+            if constexpr (DS) {
+                // identity = bf16(wd . input + bd): rounded exactly as the separate downsample launch stores it
+                f32x4 dlo = *reinterpret_cast<const f32x4*>(lds + BD_OFF + (32 * t + 8 * fq) * 4);
+                f32x4 dhi = *reinterpret_cast<const f32x4*>(lds + BD_OFF + (32 * t + 8 * fq + 4) * 4);
+                const char* drow = lds + WD_OFF + w3_frag + (2 * t) * 2048;
+                const bf16x8 pb0 = __builtin_bit_cast(bf16x8, rs[0]), pb1 = __builtin_bit_cast(bf16x8, rs[1]);
+                dlo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(drow + fphys0), pb0, dlo, 0, 0, 0);
+                dhi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(drow + 2048 + fphys0), pb0, dhi, 0, 0, 0);
+                dlo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(drow + (fphys0 ^ 64)), pb1, dlo, 0, 0, 0);
+                dhi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(drow + 2048 + (fphys0 ^ 64)), pb1, dhi, 0, 0, 0);
+                r = (u32x4){pack_bf16x2(dlo[0], dlo[1]), pack_bf16x2(dlo[2], dlo[3]), pack_bf16x2(dhi[0], dhi[1]),
+                            pack_bf16x2(dhi[2], dhi[3])};
+            } else {
+                r = rs[t];
+            }
             lo[0] += bf16_bits_to_f32(r[0] & 0xffffu); lo[1] += __uint_as_float(r[0] & 0xffff0000u);
             lo[2] += bf16_bits_to_f32(r[1] & 0xffffu); lo[3] += __uint_as_float(r[1] & 0xffff0000u);
             hi[0] += bf16_bits_to_f32(r[2] & 0xffffu); hi[1] += __uint_as_float(r[2] & 0xffff0000u);
@@ -807,7 +841,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void bneck_tail_kernel(const TailArgs
             for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
             outp[t] = o;
             __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, pix * 512u + t * 64 + fq * 16, 0, TAIL_AUX);
-            rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix_n * 512u + t * 64 + fq * 16, 0, TAIL_AUX);
+            if constexpr (!DS) rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix_n * 512u + t * 64 + fq * 16, 0, TAIL_AUX);
+        }
+        if constexpr (DS) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) rs[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix_n * 128u + kk * 64 + fq * 16, 0, 0);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) xf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_y2, pix_n * 128u + kk * 64 + fq * 16, 0, 0);

@@ -386,13 +386,25 @@ void prof_end(r50_handle* h, hipStream_t s, EvRec& r) {
     h->ev_pending.push_back(r);
 }
 
-// conv3 (64 -> 256) + identity + ReLU + next conv1 (256 -> c1) in one launch (kernels.h: bneck_tail_kernel)
-hipError_t launch_bneck_tail(const void* y2, long long m, const void* w3, const float* b3, const void* res, void* out,
-                             const void* w1, int c1, const float* b1, void* y1n, hipStream_t s) {
+// conv3 (64 -> 256) + identity + ReLU + next conv1 (256 -> c1) in one launch (kernels.h: bneck_tail_kernel).
+// wd/bd non-null: `res` is the block INPUT (m,64) and the identity is the downsample conv computed in the kernel.
+template <int C1, bool DS>
+hipError_t launch_bneck_tail_t(const TailArgs& a, int grid, hipStream_t s) {
+    const size_t lds = 256 * 128 * (DS ? 2 : 1) + (size_t)C1 * 512 + 256 * 4 * (DS ? 2 : 1) + (size_t)C1 * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_tail_kernel<C1, DS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((bneck_tail_kernel<C1, DS>), dim3(grid), dim3(TAIL_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_bneck_tail(const void* y2, long long m, const void* w3, const float* b3, const void* res, const void* wd,
+                             const float* bd, void* out, const void* w1, int c1, const float* b1, void* y1n, hipStream_t s) {
     if (!y2 || !w3 || !b3 || !res || !out || !w1 || !b1 || !y1n || m <= 0 || m * 512 >= (1ll << 31)) return hipErrorInvalidValue;
-    if (c1 != 64 && c1 != 128) return hipErrorInvalidValue;
+    if ((c1 != 64 && c1 != 128) || ((wd == nullptr) != (bd == nullptr))) return hipErrorInvalidValue;
     TailArgs a;
     a.y2 = (const __bf16*)y2; a.w3 = (const __bf16*)w3; a.b3 = b3; a.res = (const __bf16*)res; a.out = (__bf16*)out;
+    a.wd = (const __bf16*)wd; a.bd = bd;
     a.w1 = (const __bf16*)w1; a.b1 = b1; a.y1n = (__bf16*)y1n; a.M = (int)m;
     if (g_num_cus == 0) {
         int dev = 0;
@@ -401,22 +413,9 @@ hipError_t launch_bneck_tail(const void* y2, long long m, const void* w3, const 
         g_num_cus = prop.multiProcessorCount;
     }
     const long long tiles = (m + 15) / 16;
-    #ifndef TAIL_GRID_MULT
-#define TAIL_GRID_MULT 1
-#endif
-    const int grid = (int)std::min<long long>((tiles + TAIL_THREADS / 64 - 1) / (TAIL_THREADS / 64), (long long)g_num_cus * TAIL_GRID_MULT);
-    const size_t lds = 256 * 128 + (size_t)c1 * 512 + 256 * 4 + (size_t)c1 * 4;
-    hipError_t e;
-    if (c1 == 64) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_tail_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(bneck_tail_kernel<64>, dim3(grid), dim3(TAIL_THREADS), lds, s, a);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_tail_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(bneck_tail_kernel<128>, dim3(grid), dim3(TAIL_THREADS), lds, s, a);
-    }
-    return hipGetLastError();
+    const int grid = (int)std::min<long long>((tiles + TAIL_THREADS / 64 - 1) / (TAIL_THREADS / 64), (long long)g_num_cus);
+    if (wd) return c1 == 64 ? launch_bneck_tail_t<64, true>(a, grid, s) : launch_bneck_tail_t<128, true>(a, grid, s);
+    return c1 == 64 ? launch_bneck_tail_t<64, false>(a, grid, s) : launch_bneck_tail_t<128, false>(a, grid, s);
 }
 
 int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, int ww, const __bf16* res,
@@ -592,7 +591,17 @@ after_pool:
             // The downsample branch of a stage's first block only depends on the block input: it runs on a side
             // stream beside conv1 -> conv2 (fills the partially occupied last round of those launches).  Not while
             // profiling (event brackets of two streams would interleave) and not when a tap is requested.
-            const bool ds_side = (b == 0) && h->overlap_ds && !h->profile && !tap;
+            // layer1: conv3 + identity + ReLU and the next block's conv1 share one pass over the pixels; in the first
+            // block the identity (downsample conv of the block input) is computed inside that kernel as well
+            const size_t li_next = li + ((b == 0) ? 4 : 3);
+            const ConvLayer* nx = (li_next < h->convs.size()) ? &h->convs[li_next] : nullptr;
+            const bool fuse = !split && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
+                              c3.cin == 64 && c3.cout == 256 && nx->ks == 1 && nx->stride == 1 && nx->cin == 256 &&
+                              (nx->cout == 64 || nx->cout == 128);
+            const ConvLayer* cdp = (b == 0) ? &h->convs[li + 3] : nullptr;
+            const bool fuse_ds = fuse && cdp && cdp->ks == 1 && cdp->stride == 1 && cdp->cin == 64 && cdp->cout == 256 &&
+                                 !(tap && p + ".ds" == tap);
+            const bool ds_side = (b == 0) && h->overlap_ds && !h->profile && !tap && !fuse_ds;
             hipStream_t sd = s;
             const __bf16* idn = buf[cur];
             int rc;
@@ -620,7 +629,7 @@ after_pool:
             rc = run_conv(h, c2, buf[fr[0]], n, h1, w1, nullptr, buf[fr[1]], 1, s, &h2, &w2);
             if (rc) return rc;
             if (hit(p + ".t2", buf[fr[1]], h2, w2, c2.cout)) return R50_OK;
-            if (b == 0 && !ds_side) {
+            if (b == 0 && !ds_side && !fuse_ds) {
                 const ConvLayer& cd = h->convs[li + 3];
                 int hd, wd;
                 rc = run_conv(h, cd, buf[cur], n, hh, ww, nullptr, buf[fr[2]], 0, s, &hd, &wd);
@@ -629,18 +638,14 @@ after_pool:
                 idn = buf[fr[2]];
             }
             if (ds_side) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_ds_join, 0));   // conv3 needs the downsample output
-            // layer1: conv3 + identity + ReLU and the next block's conv1 share one pass over the pixels
-            const size_t li_next = li + ((b == 0) ? 4 : 3);
-            const ConvLayer* nx = (li_next < h->convs.size()) ? &h->convs[li_next] : nullptr;
-            const bool fuse = !split && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
-                              c3.cin == 64 && c3.cout == 256 && nx->ks == 1 && nx->stride == 1 && nx->cin == 256 &&
-                              (nx->cout == 64 || nx->cout == 128);
             if (fuse) {
                 const long long m = (long long)n * h2 * w2;
                 EvRec rt{};
-                prof_begin(h, s, rt, PC_TAIL, 2.0 * m * (256.0 * 64 + (double)nx->cout * 256),
-                           2.0 * (m * (64.0 + 256 + 256 + nx->cout) + 256.0 * 64 + 256.0 * nx->cout), (int)(&c3 - &h->convs[0]));
-                e = launch_bneck_tail(buf[fr[1]], m, c3.w, c3.bias, idn, buf[fr[3]], nx->w, nx->cout, nx->bias, buf[fr[0]], s);
+                prof_begin(h, s, rt, PC_TAIL, 2.0 * m * (256.0 * 64 * (fuse_ds ? 2 : 1) + (double)nx->cout * 256),
+                           2.0 * (m * (64.0 + (fuse_ds ? 64 : 256) + 256 + nx->cout) + 256.0 * 64 * (fuse_ds ? 2 : 1) + 256.0 * nx->cout),
+                           (int)(&c3 - &h->convs[0]));
+                e = launch_bneck_tail(buf[fr[1]], m, c3.w, c3.bias, fuse_ds ? buf[cur] : idn, fuse_ds ? cdp->w : nullptr,
+                                      fuse_ds ? cdp->bias : nullptr, buf[fr[3]], nx->w, nx->cout, nx->bias, buf[fr[0]], s);
                 prof_end(h, s, rt);
                 if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_tail launch (" + c3.conv_key + "): " + hipGetErrorString(e));
                 h3 = h2; w3 = w2;
@@ -981,9 +986,9 @@ int r50_op_conv2d(const void* x, int n, int h, int w, int cin, const void* wt, c
     return R50_OK;
 }
 
-int r50_op_bneck_tail(const void* y2, int64_t m, const void* w3, const float* b3, const void* res, void* out, const void* w1,
-                      int c1, const float* b1, void* y1n, void* stream) {
-    hipError_t e = launch_bneck_tail(y2, m, w3, b3, res, out, w1, c1, b1, y1n, (hipStream_t)stream);
+int r50_op_bneck_tail(const void* y2, int64_t m, const void* w3, const float* b3, const void* res, const void* wd,
+                      const float* bd, void* out, const void* w1, int c1, const float* b1, void* y1n, void* stream) {
+    hipError_t e = launch_bneck_tail(y2, m, w3, b3, res, wd, bd, out, w1, c1, b1, y1n, (hipStream_t)stream);
     if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
                                      std::string("r50_op_bneck_tail: ") + hipGetErrorString(e));
     return R50_OK;

@@ -137,10 +137,14 @@ int r50_op_maxpool(const void* x_nhwc_bf16, int n, int h, int w, int c, void* y_
  * next block's conv1 1x1 (256 -> c1, c1 in {64,128}) + bn1 + ReLU -> y1n (m,c1).  Replaces, for two consecutive
  * torchvision Bottleneck blocks, `out = relu(bn3(conv3(out)) + identity)` of the first and
  * `out = relu(bn1(conv1(x)))` of the second (upstream torchvision models/resnet.py Bottleneck.forward; the
- * reference builds them at src/preprocess_resnet_features.py:207).  All tensors bf16 NHWC with m = n*h*w pixels,
- * weights folded (cout, cin) K-contiguous, biases fp32. */
+ * reference builds them at src/preprocess_resnet_features.py:207).
+ * wd/bd NULL: `identity` is the (m,256) identity tensor.  wd/bd given (the stage's first block): `identity` is the
+ * block INPUT (m,64) and the identity is `downsample(x)` = bf16(wd . x + bd), computed in the kernel with the
+ * same rounding as a separate launch.  All tensors bf16 NHWC with m = n*h*w pixels, weights folded (cout, cin)
+ * K-contiguous, biases fp32. */
 int r50_op_bneck_tail(const void* y2_bf16, int64_t m, const void* w3_bf16, const float* b3, const void* identity_bf16,
-                      void* out_bf16, const void* w1_bf16, int c1, const float* b1, void* y1n_bf16, void* stream);
+                      const void* wd_bf16, const float* bd, void* out_bf16, const void* w1_bf16, int c1, const float* b1,
+                      void* y1n_bf16, void* stream);
 
 /* AdaptiveAvgPool2d((1,1)) + flatten(1): (n,hw,c) bf16 -> (n,c) fp32; c % 8 == 0. */
 int r50_op_avgpool(const void* x_nhwc_bf16, int n, int hw, int c, float* y_f32, void* stream);

@@ -99,9 +99,10 @@ def test_conv2d_matches_oracle(lib_built, case):
         assert bool((buf[numel:] == -7.0).all()), f"conv tile={tile}: wrote past the end of the output"
 
 
+@pytest.mark.parametrize("ds", [False, True], ids=["identity", "downsample"])
 @pytest.mark.parametrize("shape,c1", [((2, 7, 9), 64), ((1, 56, 56), 128), ((3, 5, 16), 64), ((5, 56, 56), 64)],
                          ids=lambda v: str(v).replace(" ", ""))
-def test_bneck_tail_matches_oracle_and_unfused(lib_built, shape, c1):
+def test_bneck_tail_matches_oracle_and_unfused(lib_built, shape, c1, ds):
     """Fused layer1 tail (conv3 + identity + ReLU, then the next conv1 + ReLU) against the oracle's two fused-op
     emulations chained, and bit-for-bit against the two igemm launches it replaces.  Pixel counts that are not a
     multiple of 16 exercise the descriptor-clamped last tile; a guard band checks nothing is stored past M."""
@@ -112,16 +113,28 @@ def test_bneck_tail_matches_oracle_and_unfused(lib_built, shape, c1):
     y2 = _rand_bf16((n, 64, h, w), g)
     w3 = _rand_bf16((256, 64, 1, 1), g, scale=(2.0 / 64) ** 0.5)
     b3 = torch.randn(256, generator=g) * 0.1
-    idn = _rand_bf16((n, 256, h, w), g)
     w1 = _rand_bf16((c1, 256, 1, 1), g, scale=(2.0 / 256) ** 0.5)
     b1 = torch.randn(c1, generator=g) * 0.1
-    out_ref = conv_bias_act_emulated(y2.float(), w3.float(), b3, 1, 0, True, residual_bf=idn.float())
     d = _dev()
     y2d = y2.permute(0, 2, 3, 1).contiguous().to(d)
-    idd = idn.permute(0, 2, 3, 1).contiguous().to(d)
     w3d, w1d = w3.view(256, 64).contiguous().to(d), w1.view(c1, 256).contiguous().to(d)
     b3d, b1d = b3.to(d), b1.to(d)
-    out, y1n = ops.bneck_tail_bf16(y2d, w3d, b3d, idd, w1d, b1d)
+    if ds:      # first block of the stage: identity = downsample(block input), computed inside the kernel
+        xin = _rand_bf16((n, 64, h, w), g)
+        wd = _rand_bf16((256, 64, 1, 1), g, scale=(1.0 / 64) ** 0.5)
+        bd = torch.randn(256, generator=g) * 0.1
+        idn = conv_bias_act_emulated(xin.float(), wd.float(), bd, 1, 0, False)
+        xind = xin.permute(0, 2, 3, 1).contiguous().to(d)
+        wdd, bdd = wd.view(256, 64).contiguous().to(d), bd.to(d)
+        idd = ops.conv2d_bf16(xind, wdd.view(256, 1, 1, 64), bdd, relu=False, tile=ops.TILE_64x128)
+        _check_bf16(idd, idn, "downsample identity")
+        idn = idd.float().cpu().permute(0, 3, 1, 2)        # chain the oracle from the device's identity (see below)
+        out, y1n = ops.bneck_tail_bf16(y2d, w3d, b3d, xind, w1d, b1d, wd=wdd, bd=bdd)
+    else:
+        idn = _rand_bf16((n, 256, h, w), g)
+        idd = idn.permute(0, 2, 3, 1).contiguous().to(d)
+        out, y1n = ops.bneck_tail_bf16(y2d, w3d, b3d, idd, w1d, b1d)
+    out_ref = conv_bias_act_emulated(y2.float(), w3.float(), b3, 1, 0, True, residual_bf=idn.float())
     torch.cuda.synchronize()
     _check_bf16(out, out_ref, "bneck_tail out")
     # the second GEMM reads the DEVICE's bf16 block output, so chain the oracle from it (one-ulp flips of `out`

@@ -194,7 +194,8 @@ def test_fused_bottleneck_tail_equals_unfused(setup):
     bb, x, *_ = setup
     xd = x.to("cuda:0")
     assert bb.get_option("fuse_tail") == 1
-    names = ["layer1.0", "layer1.1.t1", "layer1.1", "layer1.2.t1", "layer1.2", "layer2.0.t1", "layer2.0.ds", "layer2.0"]
+    names = ["layer1.0.ds", "layer1.0", "layer1.1.t1", "layer1.1", "layer1.2.t1", "layer1.2", "layer2.0.t1", "layer2.0.ds",
+             "layer2.0"]
     fused = {k: bb.layer(xd, k).clone() for k in names}
     f1 = bb.features(xd).clone()
     bb.set_option("fuse_tail", 0)
