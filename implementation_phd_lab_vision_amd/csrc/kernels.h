@@ -881,6 +881,174 @@ __global__ __launch_bounds__(TAIL_THREADS) void bneck_tail_kernel(const TailArgs
 }
 
 // ------------------------------------------------------------------------------------------------
+// Bottleneck tail (layer2): conv3 1x1 (128 -> 512) + bn3 + identity + ReLU, and the NEXT block's conv1 1x1
+// (512 -> 128) + bn1 + ReLU, in one pass over the pixels.  Same idea as bneck_tail_kernel, but 256 KB of
+// weights do not fit LDS, so the CHANNELS are split over the 8 waves of a workgroup instead of the pixels:
+// wave w owns block-output channels [64w, 64w+64) of the workgroup's 16 pixels.  Its slice of both weight
+// matrices -- conv3 rows 64w.. (16 A fragments) and next-conv1 columns 64w.. (16 A fragments) -- lives in
+// REGISTERS for the whole launch; activations go global -> B fragments directly.  The second GEMM sums over
+// all 512 channels, i.e. over the waves: every wave writes its fp32 partial (128 couts x 16 pixels) to LDS,
+// one barrier, then wave w adds the eight partials of couts [16w, 16w+16) in a fixed order (deterministic),
+// adds the bias, ReLU, bf16, stores.  Partial buffers alternate so one barrier per step suffices.
+// The fp32 summation order of the second conv differs from the igemm's (8 partial sums instead of one
+// chain), so this path is compared with the oracle under the usual bf16 tolerance, not bit-for-bit with the
+// two launches it replaces; conv3's output IS bit-identical.
+// ------------------------------------------------------------------------------------------------
+struct Tail2Args {
+    const __bf16* y2;     // (M, 128)  conv2 output
+    const __bf16* w3;     // (512, 128)
+    const float* b3;      // (512)
+    const __bf16* res;    // (M, 512)  identity
+    __bf16* out;          // (M, 512)  block output
+    const __bf16* w1;     // (128, 512) next block's conv1
+    const float* b1;      // (128)
+    __bf16* y1n;          // (M, 128)
+    int M;
+};
+
+#define TAIL2_PF 3      // steps of input prefetch = depth of the unrolled register ring in the step loop
+__global__ __launch_bounds__(512) void bneck_tail2_kernel(const Tail2Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PART_BYTES = 8 * 8 * 1024;                 // [wave][m2] x 1 KiB (f32x4 per lane)
+    constexpr int B3_OFF = 2 * PART_BYTES;
+    constexpr int Y_OFF = B3_OFF + 512 * 4;                  // two 4-KiB images of conv2's output (16 pixels x 256 B)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int cbase = wave * 64;
+
+    for (int i = tid; i < 512; i += 512) reinterpret_cast<float*>(smem + B3_OFF)[i] = a.b3[i];
+
+    // conv3 rows of this wave, permuted so a lane ends up with 8 consecutive channels (see igemm_bf16_kernel)
+    bf16x8 a3[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int rho = 16 * m + fr;
+        const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            a3[m][kk] = *reinterpret_cast<const bf16x8*>(a.w3 + (size_t)(cbase + cl) * 128 + kk * 32 + fq * 8);
+    }
+    // next conv1: all 128 rows, this wave's 64 K columns
+    bf16x8 a1[8][2];
+#pragma unroll
+    for (int m2 = 0; m2 < 8; ++m2)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            a1[m2][t] = *reinterpret_cast<const bf16x8*>(a.w1 + (size_t)(16 * m2 + fr) * 512 + cbase + 32 * t + fq * 8);
+    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.b1 + 16 * wave + 4 * fq);
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rs_y2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.y2), 0, (unsigned)a.M * 256u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.M * 1024u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.M * 1024u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.M * 256u, 0x00020000);
+
+    const int nsteps = (a.M + 15) >> 4;
+    const int gstride = gridDim.x;
+    // conv2's output of a step (16 pixels x 256 B) is needed by all 8 waves: waves 0..3 fetch a quarter each with
+    // ONE full-row instruction (4 pixels x 256 B) and park it in LDS, every wave reads its B fragments from there.
+    // (Eight waves each loading the fragments themselves is 32 more address-unit instructions of 16 half-lines per
+    // step -- the address unit, not HBM, then sets the pace.)  Row image: 16-B chunk c of pixel p at p*256 + ((c ^ p) << 4).
+    const int ypix = 4 * wave + (lane >> 4), ychunk = lane & 15;        // waves 0..3 only
+    const int y_wr = ypix * 256 + ((ychunk ^ ypix) << 4);
+    auto load_y = [&](int st) -> u32x4 {
+        return __builtin_amdgcn_raw_buffer_load_b128(rs_y2, (unsigned)(st * 16 + ypix) * 256u + ychunk * 16, 0, 0);
+    };
+    auto load_r = [&](int st, u32x4 (&r)[2]) {
+        const unsigned pix = (unsigned)(st * 16 + fr);              // past M: the descriptor returns zeros
+#pragma unroll
+        for (int t = 0; t < 2; ++t) r[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix * 1024u + (cbase + 32 * t + 8 * fq) * 2, 0, 0);
+    };
+    // One step = 16 pixels.  `rs` holds this step's identity slice and `yn` (waves 0..3) the NEXT step's quarter of
+    // conv2's output; once consumed, the loads for TAIL2_PF steps later go into the same registers (no register
+    // moves: moving a load's destination would wait for the load).
+    auto do_step = [&](int step, int par, u32x4 (&rs)[2], u32x4& yn) {
+        const unsigned pix = (unsigned)(step * 16 + fr);
+        const char* ycur = smem + Y_OFF + par * 4096;
+        // ---- conv3 slice: 64 couts x 16 pixels, K = 128
+        u32x4 outp[2];
+        bf16x8 xb[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const bf16x8*>(ycur + fr * 256 + (((kk * 4 + fq) ^ fr) << 4));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 lo = *reinterpret_cast<const f32x4*>(smem + B3_OFF + (cbase + 32 * t + 8 * fq) * 4);
+            f32x4 hi = *reinterpret_cast<const f32x4*>(smem + B3_OFF + (cbase + 32 * t + 8 * fq + 4) * 4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[2 * t][kk], xb[kk], lo, 0, 0, 0);
+                hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[2 * t + 1][kk], xb[kk], hi, 0, 0, 0);
+            }
+            const u32x4 r = rs[t];
+            lo[0] += bf16_bits_to_f32(r[0] & 0xffffu); lo[1] += __uint_as_float(r[0] & 0xffff0000u);
+            lo[2] += bf16_bits_to_f32(r[1] & 0xffffu); lo[3] += __uint_as_float(r[1] & 0xffff0000u);
+            hi[0] += bf16_bits_to_f32(r[2] & 0xffffu); hi[1] += __uint_as_float(r[2] & 0xffff0000u);
+            hi[2] += bf16_bits_to_f32(r[3] & 0xffffu); hi[3] += __uint_as_float(r[3] & 0xffff0000u);
+            u32x4 o = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                              pack_bf16x2(hi[2], hi[3])};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+            outp[t] = o;
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, pix * 1024u + (cbase + 32 * t + 8 * fq) * 2, 0, 0);
+        }
+        load_r(step + TAIL2_PF * gstride, rs);
+        if (wave < 4) {
+            *reinterpret_cast<u32x4*>(smem + Y_OFF + (par ^ 1) * 4096 + y_wr) = yn;       // next step's conv2 output
+            yn = load_y(step + (TAIL2_PF + 1) * gstride);
+        }
+        // ---- next conv1, this wave's 64 of the 512 K channels: partial (128 couts x 16 pixels) to LDS
+        char* part = smem + par * PART_BYTES;
+#pragma unroll
+        for (int m2 = 0; m2 < 8; ++m2) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[m2][t], __builtin_bit_cast(bf16x8, outp[t]), acc, 0, 0, 0);
+            *reinterpret_cast<f32x4*>(part + (wave * 8 + m2) * 1024 + lane * 16) = acc;
+        }
+        // NOT __syncthreads(): that also drains vmcnt, i.e. waits for every prefetch and store in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- wave w reduces couts [16w, 16w+16): fixed order over the eight channel slices
+        f32x4 sum = *reinterpret_cast<const f32x4*>(part + (0 * 8 + wave) * 1024 + lane * 16);
+#pragma unroll
+        for (int w2 = 1; w2 < 8; ++w2) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(part + (w2 * 8 + wave) * 1024 + lane * 16);
+            sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; sum[3] += p[3];
+        }
+        sum[0] += bias1[0]; sum[1] += bias1[1]; sum[2] += bias1[2]; sum[3] += bias1[3];
+        const unsigned o0 = relu_bf16x2(pack_bf16x2(sum[0], sum[1])), o1 = relu_bf16x2(pack_bf16x2(sum[2], sum[3]));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64((u32x2){o0, o1}, rs_y1, pix * 256u + (16 * wave + 4 * fq) * 2, 0, 0);
+    };
+    u32x4 rsA[2], rsB[2], rsC[2], yA = {0, 0, 0, 0}, yB = {0, 0, 0, 0}, yC = {0, 0, 0, 0};
+    int step = blockIdx.x;
+    if (wave < 4) {
+        const u32x4 y0 = load_y(step);
+        yA = load_y(step + gstride); yB = load_y(step + 2 * gstride); yC = load_y(step + 3 * gstride);
+        *reinterpret_cast<u32x4*>(smem + Y_OFF + y_wr) = y0;
+    }
+    load_r(step, rsA); load_r(step + gstride, rsB); load_r(step + 2 * gstride, rsC);
+    __syncthreads();
+    // every wave of the workgroup runs the same steps (there is a barrier inside do_step); the LDS buffers alternate
+    int par = 0;
+    while (step < nsteps) {
+        do_step(step, par, rsA, yA); step += gstride; par ^= 1;
+        if (step >= nsteps) break;
+        do_step(step, par, rsB, yB); step += gstride; par ^= 1;
+        if (step >= nsteps) break;
+        do_step(step, par, rsC, yC); step += gstride; par ^= 1;
+    }
+#else
+    (void)a;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stem, step 1: fp32 NCHW (N,3,224,224) -> bf16 "NHWC4" with a zero border:
 //   xp[n][hp][wp][4], hp = hi + 3 in [0,230), wp = wi + 4 in [0,232); channel 3 = 0.
 // One thread per output pixel (8 B).  The border is rewritten every call.

@@ -418,6 +418,28 @@ hipError_t launch_bneck_tail(const void* y2, long long m, const void* w3, const 
     return c1 == 64 ? launch_bneck_tail_t<64, false>(a, grid, s) : launch_bneck_tail_t<128, false>(a, grid, s);
 }
 
+// layer2 shapes: conv3 (128 -> 512) + identity + ReLU + next conv1 (512 -> 128) (kernels.h: bneck_tail2_kernel)
+hipError_t launch_bneck_tail2(const void* y2, long long m, const void* w3, const float* b3, const void* res, void* out,
+                              const void* w1, const float* b1, void* y1n, hipStream_t s) {
+    if (!y2 || !w3 || !b3 || !res || !out || !w1 || !b1 || !y1n || m <= 0 || m * 1024 >= (1ll << 31)) return hipErrorInvalidValue;
+    Tail2Args a;
+    a.y2 = (const __bf16*)y2; a.w3 = (const __bf16*)w3; a.b3 = b3; a.res = (const __bf16*)res; a.out = (__bf16*)out;
+    a.w1 = (const __bf16*)w1; a.b1 = b1; a.y1n = (__bf16*)y1n; a.M = (int)m;
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        g_num_cus = prop.multiProcessorCount;
+    }
+    const long long steps = (m + 15) / 16;
+    const int grid = (int)std::min<long long>(steps, (long long)g_num_cus);
+    const size_t lds = 2 * 8 * 8 * 1024 + 512 * 4 + 2 * 4096;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_tail2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bneck_tail2_kernel, dim3(grid), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, int ww, const __bf16* res,
              __bf16* y, int relu, hipStream_t s, int* ho, int* wo) {
     ConvArgs a;
@@ -595,9 +617,11 @@ after_pool:
             // block the identity (downsample conv of the block input) is computed inside that kernel as well
             const size_t li_next = li + ((b == 0) ? 4 : 3);
             const ConvLayer* nx = (li_next < h->convs.size()) ? &h->convs[li_next] : nullptr;
-            const bool fuse = !split && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
-                              c3.cin == 64 && c3.cout == 256 && nx->ks == 1 && nx->stride == 1 && nx->cin == 256 &&
-                              (nx->cout == 64 || nx->cout == 128);
+            const bool fuse_ok = !split && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
+                                 nx->ks == 1 && nx->stride == 1;
+            const bool fuse2 = fuse_ok && c3.cin == 128 && c3.cout == 512 && nx->cin == 512 && nx->cout == 128;   // layer2 shapes
+            const bool fuse = (fuse_ok && c3.cin == 64 && c3.cout == 256 && nx->cin == 256 && (nx->cout == 64 || nx->cout == 128)) ||
+                              fuse2;
             const ConvLayer* cdp = (b == 0) ? &h->convs[li + 3] : nullptr;
             const bool fuse_ds = fuse && cdp && cdp->ks == 1 && cdp->stride == 1 && cdp->cin == 64 && cdp->cout == 256 &&
                                  !(tap && p + ".ds" == tap);
@@ -641,11 +665,15 @@ after_pool:
             if (fuse) {
                 const long long m = (long long)n * h2 * w2;
                 EvRec rt{};
-                prof_begin(h, s, rt, PC_TAIL, 2.0 * m * (256.0 * 64 * (fuse_ds ? 2 : 1) + (double)nx->cout * 256),
-                           2.0 * (m * (64.0 + (fuse_ds ? 64 : 256) + 256 + nx->cout) + 256.0 * 64 * (fuse_ds ? 2 : 1) + 256.0 * nx->cout),
+                prof_begin(h, s, rt, PC_TAIL, 2.0 * m * ((double)c3.cout * c3.cin * (fuse_ds ? 2 : 1) + (double)nx->cout * nx->cin),
+                           2.0 * (m * ((double)c3.cin + (fuse_ds ? c3.cin : c3.cout) + c3.cout + nx->cout) +
+                                  (double)c3.cout * c3.cin * (fuse_ds ? 2 : 1) + (double)nx->cin * nx->cout),
                            (int)(&c3 - &h->convs[0]));
-                e = launch_bneck_tail(buf[fr[1]], m, c3.w, c3.bias, fuse_ds ? buf[cur] : idn, fuse_ds ? cdp->w : nullptr,
-                                      fuse_ds ? cdp->bias : nullptr, buf[fr[3]], nx->w, nx->cout, nx->bias, buf[fr[0]], s);
+                if (fuse2)
+                    e = launch_bneck_tail2(buf[fr[1]], m, c3.w, c3.bias, idn, buf[fr[3]], nx->w, nx->bias, buf[fr[0]], s);
+                else
+                    e = launch_bneck_tail(buf[fr[1]], m, c3.w, c3.bias, fuse_ds ? buf[cur] : idn, fuse_ds ? cdp->w : nullptr,
+                                          fuse_ds ? cdp->bias : nullptr, buf[fr[3]], nx->w, nx->cout, nx->bias, buf[fr[0]], s);
                 prof_end(h, s, rt);
                 if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_tail launch (" + c3.conv_key + "): " + hipGetErrorString(e));
                 h3 = h2; w3 = w2;
@@ -986,9 +1014,12 @@ int r50_op_conv2d(const void* x, int n, int h, int w, int cin, const void* wt, c
     return R50_OK;
 }
 
-int r50_op_bneck_tail(const void* y2, int64_t m, const void* w3, const float* b3, const void* res, const void* wd,
+int r50_op_bneck_tail(const void* y2, int64_t m, int cmid, const void* w3, const float* b3, const void* res, const void* wd,
                       const float* bd, void* out, const void* w1, int c1, const float* b1, void* y1n, void* stream) {
-    hipError_t e = launch_bneck_tail(y2, m, w3, b3, res, wd, bd, out, w1, c1, b1, y1n, (hipStream_t)stream);
+    hipError_t e;
+    if (cmid == 64) e = launch_bneck_tail(y2, m, w3, b3, res, wd, bd, out, w1, c1, b1, y1n, (hipStream_t)stream);
+    else if (cmid == 128 && c1 == 128 && !wd && !bd) e = launch_bneck_tail2(y2, m, w3, b3, res, out, w1, b1, y1n, (hipStream_t)stream);
+    else e = hipErrorInvalidValue;
     if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
                                      std::string("r50_op_bneck_tail: ") + hipGetErrorString(e));
     return R50_OK;

@@ -74,29 +74,32 @@ def conv2d_bf16(x: torch.Tensor, w_ohwi: torch.Tensor, bias: torch.Tensor, strid
 
 def bneck_tail_bf16(y2: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, identity: torch.Tensor, w1: torch.Tensor,
                     b1: torch.Tensor, wd: Optional[torch.Tensor] = None, bd: Optional[torch.Tensor] = None):
-    """Fused tail of a layer1 bottleneck: ``out = relu(conv3(y2) + b3 + identity)`` and the next block's
-    ``y1n = relu(conv1(out) + b1)``.  y2 (...,64), w3 (256,64) / w1 (c1,256) folded bf16, biases fp32 ->
-    (out (...,256), y1n (...,c1)) bf16.  ``identity`` is the (...,256) identity tensor, or -- with the folded
-    downsample weights ``wd`` (256,64) / ``bd`` -- the (...,64) block input."""
+    """Fused tail of a bottleneck: ``out = relu(conv3(y2) + b3 + identity)`` and the next block's
+    ``y1n = relu(conv1(out) + b1)``.  y2 (...,cmid), w3 (4*cmid,cmid) / w1 (c1,4*cmid) folded bf16, biases fp32 ->
+    (out (...,4*cmid), y1n (...,c1)) bf16; cmid = 64 (layer1) or 128 (layer2, c1 = 128).  ``identity`` is the
+    (...,4*cmid) identity tensor, or -- cmid = 64 with the folded downsample weights ``wd`` (256,64) / ``bd`` --
+    the (...,64) block input."""
     for t, n in ((y2, "y2"), (w3, "w3"), (identity, "identity"), (w1, "w1")):
         _need(t, torch.bfloat16, n)
     _need(b3, torch.float32, "b3"); _need(b1, torch.float32, "b1")
-    m = y2.numel() // 64
+    cmid = y2.shape[-1]
+    cout = 4 * cmid
+    m = y2.numel() // cmid
     c1 = w1.shape[0]
-    cid = 256 if wd is None else 64
+    cid = cout if wd is None else cmid
     if (wd is None) != (bd is None):
         raise ValueError("bneck_tail_bf16: wd and bd go together")
     if wd is not None:
         _need(wd, torch.bfloat16, "wd"); _need(bd, torch.float32, "bd")
-        if tuple(wd.shape) != (256, 64) or bd.numel() != 256:
+        if tuple(wd.shape) != (cout, cmid) or bd.numel() != cout:
             raise ValueError("bneck_tail_bf16: inconsistent downsample shapes")
-    if y2.shape[-1] != 64 or identity.shape[-1] != cid or identity.numel() != m * cid or tuple(w3.shape) != (256, 64) \
-            or tuple(w1.shape) != (c1, 256) or b3.numel() != 256 or b1.numel() != c1:
+    if identity.shape[-1] != cid or identity.numel() != m * cid or tuple(w3.shape) != (cout, cmid) \
+            or tuple(w1.shape) != (c1, cout) or b3.numel() != cout or b1.numel() != c1:
         raise ValueError("bneck_tail_bf16: inconsistent shapes")
-    out = torch.empty(tuple(y2.shape[:-1]) + (256,), dtype=torch.bfloat16, device=y2.device)
+    out = torch.empty(tuple(y2.shape[:-1]) + (cout,), dtype=torch.bfloat16, device=y2.device)
     y1n = torch.empty(tuple(y2.shape[:-1]) + (c1,), dtype=torch.bfloat16, device=y2.device)
     with torch.cuda.device(y2.device):
-        rc = _lib.load_library().r50_op_bneck_tail(y2.data_ptr(), m, w3.data_ptr(), b3.data_ptr(), identity.data_ptr(),
+        rc = _lib.load_library().r50_op_bneck_tail(y2.data_ptr(), m, cmid, w3.data_ptr(), b3.data_ptr(), identity.data_ptr(),
                                                    wd.data_ptr() if wd is not None else None,
                                                    bd.data_ptr() if bd is not None else None,
                                                    out.data_ptr(), w1.data_ptr(), c1, b1.data_ptr(), y1n.data_ptr(), _stream(y2))

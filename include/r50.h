@@ -133,18 +133,20 @@ int r50_op_stem(const float* x_nchw_f32_dev, int n, const float* w_oihw_f32_host
 /* MaxPool2d(3, stride 2, pad 1) on bf16 NHWC; c % 8 == 0. */
 int r50_op_maxpool(const void* x_nhwc_bf16, int n, int h, int w, int c, void* y_nhwc_bf16, void* stream);
 
-/* Bottleneck tail of layer1 in one launch: conv3 1x1 (64 -> 256) + bn3 + identity + ReLU -> out (m,256), and the
- * next block's conv1 1x1 (256 -> c1, c1 in {64,128}) + bn1 + ReLU -> y1n (m,c1).  Replaces, for two consecutive
- * torchvision Bottleneck blocks, `out = relu(bn3(conv3(out)) + identity)` of the first and
- * `out = relu(bn1(conv1(x)))` of the second (upstream torchvision models/resnet.py Bottleneck.forward; the
- * reference builds them at src/preprocess_resnet_features.py:207).
- * wd/bd NULL: `identity` is the (m,256) identity tensor.  wd/bd given (the stage's first block): `identity` is the
- * block INPUT (m,64) and the identity is `downsample(x)` = bf16(wd . x + bd), computed in the kernel with the
- * same rounding as a separate launch.  All tensors bf16 NHWC with m = n*h*w pixels, weights folded (cout, cin)
- * K-contiguous, biases fp32. */
-int r50_op_bneck_tail(const void* y2_bf16, int64_t m, const void* w3_bf16, const float* b3, const void* identity_bf16,
-                      const void* wd_bf16, const float* bd, void* out_bf16, const void* w1_bf16, int c1, const float* b1,
-                      void* y1n_bf16, void* stream);
+/* Bottleneck tail in one launch: conv3 1x1 (cmid -> 4*cmid) + bn3 + identity + ReLU -> out (m,4*cmid), and the
+ * next block's conv1 1x1 (4*cmid -> c1) + bn1 + ReLU -> y1n (m,c1).  Replaces, for two consecutive torchvision
+ * Bottleneck blocks, `out = relu(bn3(conv3(out)) + identity)` of the first and `out = relu(bn1(conv1(x)))` of
+ * the second (upstream torchvision models/resnet.py Bottleneck.forward; the reference builds them at
+ * src/preprocess_resnet_features.py:207).  Shapes: cmid = 64 (layer1; c1 in {64,128}) or cmid = 128 (layer2;
+ * c1 = 128, no wd/bd).
+ * wd/bd NULL: `identity` is the (m,4*cmid) identity tensor.  wd/bd given (cmid = 64, the stage's first block):
+ * `identity` is the block INPUT (m,64) and the identity is `downsample(x)` = bf16(wd . x + bd), computed in
+ * the kernel with the same rounding as a separate launch.  All tensors bf16 NHWC with m = n*h*w pixels,
+ * weights folded (cout, cin) K-contiguous, biases fp32.  cmid = 64 reproduces the two separate launches bit
+ * for bit; cmid = 128 sums the second conv's K in eight slices (fp32), i.e. within rounding of them. */
+int r50_op_bneck_tail(const void* y2_bf16, int64_t m, int cmid, const void* w3_bf16, const float* b3,
+                      const void* identity_bf16, const void* wd_bf16, const float* bd, void* out_bf16, const void* w1_bf16,
+                      int c1, const float* b1, void* y1n_bf16, void* stream);
 
 /* AdaptiveAvgPool2d((1,1)) + flatten(1): (n,hw,c) bf16 -> (n,c) fp32; c % 8 == 0. */
 int r50_op_avgpool(const void* x_nhwc_bf16, int n, int hw, int c, float* y_f32, void* stream);

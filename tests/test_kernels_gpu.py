@@ -147,6 +147,36 @@ def test_bneck_tail_matches_oracle_and_unfused(lib_built, shape, c1, ds):
     assert torch.equal(y1n, y1_u), "fused next-conv1 output differs from the igemm launch it replaces"
 
 
+@pytest.mark.parametrize("shape", [(2, 7, 9), (1, 28, 28), (3, 5, 16), (9, 28, 28)], ids=lambda v: str(v).replace(" ", ""))
+def test_bneck_tail_layer2_shapes(lib_built, shape):
+    """Fused layer2 tail (conv3 128->512 + identity + ReLU, next conv1 512->128 + ReLU; channels split over the waves,
+    second conv reduced through LDS).  conv3's output must equal the igemm launch bit for bit; the second conv sums
+    its K in eight slices, so it is held to the oracle under the bf16 tolerance."""
+    from implementation_phd_lab_vision_amd import ops
+    from oracle.resnet50_oracle import conv_bias_act_emulated
+    n, h, w = shape
+    g = torch.Generator().manual_seed(2000 + n * h * w)
+    y2 = _rand_bf16((n, 128, h, w), g)
+    w3 = _rand_bf16((512, 128, 1, 1), g, scale=(2.0 / 128) ** 0.5)
+    b3 = torch.randn(512, generator=g) * 0.1
+    idn = _rand_bf16((n, 512, h, w), g)
+    w1 = _rand_bf16((128, 512, 1, 1), g, scale=(2.0 / 512) ** 0.5)
+    b1 = torch.randn(128, generator=g) * 0.1
+    d = _dev()
+    y2d = y2.permute(0, 2, 3, 1).contiguous().to(d)
+    idd = idn.permute(0, 2, 3, 1).contiguous().to(d)
+    w3d, w1d = w3.view(512, 128).contiguous().to(d), w1.view(128, 512).contiguous().to(d)
+    b3d, b1d = b3.to(d), b1.to(d)
+    out, y1n = ops.bneck_tail_bf16(y2d, w3d, b3d, idd, w1d, b1d)
+    torch.cuda.synchronize()
+    out_ref = conv_bias_act_emulated(y2.float(), w3.float(), b3, 1, 0, True, residual_bf=idn.float())
+    _check_bf16(out, out_ref, "bneck_tail2 out")
+    y1_ref = conv_bias_act_emulated(out.float().cpu().permute(0, 3, 1, 2), w1.float(), b1, 1, 0, True)
+    _check_bf16(y1n, y1_ref, "bneck_tail2 y1n")
+    out_u = ops.conv2d_bf16(y2d, w3d.view(512, 1, 1, 128), b3d, relu=True, residual=idd, tile=ops.TILE_64x128)
+    assert torch.equal(out, out_u), "fused block output differs from the igemm launch it replaces"
+
+
 def test_conv2d_identity_asymmetric(lib_built):
     """A = I check with an asymmetric B (cdna guide §3): 1x1 conv with identity weights must return
     the input exactly; a transposed operand or C/D map cannot pass."""

@@ -189,20 +189,27 @@ def test_fused_stem_equals_unfused(setup):
 
 
 def test_fused_bottleneck_tail_equals_unfused(setup):
-    """layer1: conv3 + identity + ReLU + the next block's conv1 in one kernel must give, bit for bit, what the two
-    igemm launches give -- at every tap the fusion touches and at the final features."""
+    """conv3 + identity + ReLU + the next block's conv1 in one kernel.  layer1 (pixels split over the waves): bit
+    for bit what the two igemm launches give.  layer2 (channels split over the waves, second conv summed in eight
+    K slices): block outputs downstream of a fused conv1 may flip a bf16 ulp, so those are held to a tight rel-L2."""
+    from oracle.resnet50_oracle import rel_l2
     bb, x, *_ = setup
     xd = x.to("cuda:0")
     assert bb.get_option("fuse_tail") == 1
-    names = ["layer1.0.ds", "layer1.0", "layer1.1.t1", "layer1.1", "layer1.2.t1", "layer1.2", "layer2.0.t1", "layer2.0.ds",
+    exact = ["layer1.0.ds", "layer1.0", "layer1.1.t1", "layer1.1", "layer1.2.t1", "layer1.2", "layer2.0.t1", "layer2.0.ds",
              "layer2.0"]
-    fused = {k: bb.layer(xd, k).clone() for k in names}
+    close = ["layer2.1.t1", "layer2.1", "layer2.2.t1", "layer2.3.t1", "layer2.3", "layer3.0"]
+    fused = {k: bb.layer(xd, k).clone() for k in exact + close}
     f1 = bb.features(xd).clone()
     bb.set_option("fuse_tail", 0)
     try:
-        for k in names:
+        for k in exact:
             assert torch.equal(bb.layer(xd, k), fused[k]), k
-        assert torch.equal(bb.features(xd), f1)
+        for k in close:
+            r = rel_l2(bb.layer(xd, k).float(), fused[k].float())
+            assert r < 2e-3, f"{k}: rel-L2 {r} between fused and unfused"
+        r = rel_l2(bb.features(xd), f1)
+        assert r < 2e-3, f"features: rel-L2 {r} between fused and unfused"
     finally:
         bb.set_option("fuse_tail", 1)
 
