@@ -717,14 +717,11 @@ struct TailArgs {
     int M;
 };
 
-#ifndef TAIL_THREADS
-#define TAIL_THREADS 256
-#endif
 #ifndef TAIL_AUX
 #define TAIL_AUX 0
 #endif
-template <int C1, bool DS>
-__global__ __launch_bounds__(TAIL_THREADS) void bneck_tail_kernel(const TailArgs a) {
+template <int C1, bool DS, int NT>
+__global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int W3_BYTES = 256 * 128;
     constexpr int W1_BYTES = C1 * 512;
@@ -739,29 +736,29 @@ __global__ __launch_bounds__(TAIL_THREADS) void bneck_tail_kernel(const TailArgs
     const int fr = lane & 15, fq = lane >> 4;
 
     // weights -> LDS once.  LDS row rho holds channel perm(rho) (see igemm: 8 consecutive couts per lane)
-    for (int i = tid; i < 256 * 8; i += TAIL_THREADS) {
+    for (int i = tid; i < 256 * 8; i += NT) {
         const int rho = i >> 3, c = i & 7;
         const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
         *reinterpret_cast<u32x4*>(smem + rho * 128 + ((c ^ (rho & 7)) << 4)) =
             *reinterpret_cast<const u32x4*>(a.w3 + cl * 64 + c * 8);
     }
-    for (int i = tid; i < C1 * 32; i += TAIL_THREADS) {
+    for (int i = tid; i < C1 * 32; i += NT) {
         const int rho = i >> 5, c = i & 31;
         const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
         *reinterpret_cast<u32x4*>(smem + W3_BYTES + rho * 512 + ((c ^ (rho & 15)) << 4)) =
             *reinterpret_cast<const u32x4*>(a.w1 + cl * 256 + c * 8);
     }
     if constexpr (DS) {
-        for (int i = tid; i < 256 * 8; i += TAIL_THREADS) {
+        for (int i = tid; i < 256 * 8; i += NT) {
             const int rho = i >> 3, c = i & 7;
             const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
             *reinterpret_cast<u32x4*>(smem + WD_OFF + rho * 128 + ((c ^ (rho & 7)) << 4)) =
                 *reinterpret_cast<const u32x4*>(a.wd + cl * 64 + c * 8);
         }
-        for (int i = tid; i < 256; i += TAIL_THREADS) reinterpret_cast<float*>(smem + BD_OFF)[i] = a.bd[i];
+        for (int i = tid; i < 256; i += NT) reinterpret_cast<float*>(smem + BD_OFF)[i] = a.bd[i];
     }
-    for (int i = tid; i < 256; i += TAIL_THREADS) reinterpret_cast<float*>(smem + B3_OFF)[i] = a.b3[i];
-    for (int i = tid; i < C1; i += TAIL_THREADS) reinterpret_cast<float*>(smem + B1_OFF)[i] = a.b1[i];
+    for (int i = tid; i < 256; i += NT) reinterpret_cast<float*>(smem + B3_OFF)[i] = a.b3[i];
+    for (int i = tid; i < C1; i += NT) reinterpret_cast<float*>(smem + B1_OFF)[i] = a.b1[i];
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rs_y2 =
@@ -772,7 +769,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void bneck_tail_kernel(const TailArgs
     const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.M * (C1 * 2u), 0x00020000);
 
     const int ntiles = (a.M + 15) >> 4;
-    const int nwaves = gridDim.x * (TAIL_THREADS / 64);
+    const int nwaves = gridDim.x * (NT / 64);
     const int w3_frag = fr * 128, fphys0 = (fq ^ (fr & 7)) << 4;
     const int w1_frag = W3_BYTES + fr * 512;
 
@@ -781,7 +778,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void bneck_tail_kernel(const TailArgs
     // behind this tile's stores never stalls).
     constexpr int NRS = DS ? 2 : 8;      // identity registers: 8 chunks of the identity itself, or 2 B fragments of the block input
     u32x4 xf[2], rs[NRS];
-    int tile = blockIdx.x * (TAIL_THREADS / 64) + wave;
+    int tile = blockIdx.x * (NT / 64) + wave;
     {
         const unsigned pix = (unsigned)(tile * 16 + fr);           // past M: the descriptor returns zeros
 #pragma unroll

@@ -388,16 +388,24 @@ void prof_end(r50_handle* h, hipStream_t s, EvRec& r) {
 
 // conv3 (64 -> 256) + identity + ReLU + next conv1 (256 -> c1) in one launch (kernels.h: bneck_tail_kernel).
 // wd/bd non-null: `res` is the block INPUT (m,64) and the identity is the downsample conv computed in the kernel.
-template <int C1, bool DS>
-hipError_t launch_bneck_tail_t(const TailArgs& a, int grid, hipStream_t s) {
+template <int C1, bool DS, int NT>
+hipError_t launch_bneck_tail_t(const TailArgs& a, hipStream_t s) {
     const size_t lds = 256 * 128 * (DS ? 2 : 1) + (size_t)C1 * 512 + 256 * 4 * (DS ? 2 : 1) + (size_t)C1 * 4;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_tail_kernel<C1, DS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_tail_kernel<C1, DS, NT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((bneck_tail_kernel<C1, DS>), dim3(grid), dim3(TAIL_THREADS), lds, s, a);
+    const long long tiles = ((long long)a.M + 15) / 16;
+    const int grid = (int)std::min<long long>((tiles + NT / 64 - 1) / (NT / 64), (long long)g_num_cus);
+    hipLaunchKernelGGL((bneck_tail_kernel<C1, DS, NT>), dim3(grid), dim3(NT), lds, s, a);
     return hipGetLastError();
 }
 
+#ifndef TAIL_NT_DS
+#define TAIL_NT_DS 512
+#endif
+#ifndef TAIL_NT_C128
+#define TAIL_NT_C128 256
+#endif
 hipError_t launch_bneck_tail(const void* y2, long long m, const void* w3, const float* b3, const void* res, const void* wd,
                              const float* bd, void* out, const void* w1, int c1, const float* b1, void* y1n, hipStream_t s) {
     if (!y2 || !w3 || !b3 || !res || !out || !w1 || !b1 || !y1n || m <= 0 || m * 512 >= (1ll << 31)) return hipErrorInvalidValue;
@@ -412,10 +420,9 @@ hipError_t launch_bneck_tail(const void* y2, long long m, const void* w3, const 
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
         g_num_cus = prop.multiProcessorCount;
     }
-    const long long tiles = (m + 15) / 16;
-    const int grid = (int)std::min<long long>((tiles + TAIL_THREADS / 64 - 1) / (TAIL_THREADS / 64), (long long)g_num_cus);
-    if (wd) return c1 == 64 ? launch_bneck_tail_t<64, true>(a, grid, s) : launch_bneck_tail_t<128, true>(a, grid, s);
-    return c1 == 64 ? launch_bneck_tail_t<64, false>(a, grid, s) : launch_bneck_tail_t<128, false>(a, grid, s);
+    // 4 waves per CU stream best (more waves lower the HBM rate); the downsample variant has 1.5x the MFMA work
+    if (wd) return c1 == 64 ? launch_bneck_tail_t<64, true, TAIL_NT_DS>(a, s) : launch_bneck_tail_t<128, true, TAIL_NT_DS>(a, s);
+    return c1 == 64 ? launch_bneck_tail_t<64, false, 256>(a, s) : launch_bneck_tail_t<128, false, TAIL_NT_C128>(a, s);
 }
 
 // layer2 shapes: conv3 (128 -> 512) + identity + ReLU + next conv1 (512 -> 128) (kernels.h: bneck_tail2_kernel)
