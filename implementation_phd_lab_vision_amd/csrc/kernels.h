@@ -689,6 +689,161 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv 3x3 / stride 1 / pad 1, 64 -> 64 channels on 56x56 images (layer1.*.conv2), weights resident in LDS.
+// Why its own kernel: with Cin = Cout = 64 the whole filter bank is 72 KB, so it can stay in LDS for the launch,
+// and the input only has to be staged ONCE per tile (with its halo) instead of once per tap: the generic implicit
+// GEMM moves 24 KB from L2 into LDS per 128-pixel K-step (1.7 KB per output pixel) and its 16-MFMA steps are
+// mostly barrier and DMA-issue overhead; here it is 0.2 KB per pixel and ONE barrier per 224-pixel tile.
+// Tile = 4 output rows x 56 columns (an image is 14 tiles).  LDS: [9 taps][64 couts][128 B] weights + two input
+// images of 6 rows x 58 columns x 128 B (zero border by out-of-range DMA) = exactly 160 KB.
+// 4 consumer waves (2 cout halves x 2 pixel halves, wave tile 32 couts x 112 pixels) run 252 MFMAs per tile
+// straight from LDS; 4 loader waves DMA the next tile's input while they do.
+// Input image row: pixel (rr, col) at (rr*58 + col)*128, 16-B chunk c stored at c ^ (col & 7)  -- keyed on the
+// COLUMN so that a tap's row shift (kh*58 rows) is an immediate offset and only the 3 column shifts need their
+// own address registers.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int W_BYTES = 9 * 64 * 128;             // 73,728
+    constexpr int XROWS_LDS = 352;                    // 6*58 = 348 rows, staged in 11 passes of 32
+    constexpr int X_BYTES = XROWS_LDS * 128;          // 45,056
+    constexpr int NPASS = 11;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // filter bank -> LDS: [tap][row rho][chunk ^ (rho & 7)], row rho holds cout perm(rho) (8 consecutive couts per lane)
+    for (int i = tid; i < 9 * 64 * 8; i += 512) {
+        const int c = i & 7, rho = (i >> 3) & 63, tap = i >> 9;
+        const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+        *reinterpret_cast<u32x4*>(smem + tap * 8192 + rho * 128 + ((c ^ (rho & 7)) << 4)) =
+            *reinterpret_cast<const u32x4*>(a.w + (size_t)cl * 576 + tap * 64 + c * 8);
+    }
+    const int grid = gridDim.x;
+    const int n_tiles = a.N * 14;
+    const int first = blockIdx.x;
+    const int my_tiles = (n_tiles - first + grid - 1) / grid;
+
+    if (wave >= 4) {
+        // =============================== loader waves ===============================================
+        const int lw = wave - 4;
+        const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(a.x) - a.x_back), 0, a.x_records, 0x00020000);
+        // per pass: LDS row rho = pass*32 + lw*8 + (lane >> 3) -> (rr, col); tile-invariant
+        unsigned rel[NPASS];
+        unsigned top_mask = 0u, bot_mask = 0u, ok_mask = 0u;      // bit per pass
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int rho = i * 32 + lw * 8 + (lane >> 3);
+            const int rr = rho / 58, col = rho - rr * 58;
+            const int chunk = (lane & 7) ^ (col & 7);
+            // relative to the pixel one row above and one column left of the tile's first output pixel
+            rel[i] = (unsigned)((rr * 56 + col) * 128 + chunk * 16);
+            if (rho < 348 && col >= 1 && col <= 56) ok_mask |= 1u << i;
+            if (rr == 0) top_mask |= 1u << i;
+            if (rr == 5) bot_mask |= 1u << i;
+        }
+        auto issue = [&](int tile, int buf) {
+            const int n = tile / 14, tr = tile - n * 14;
+            // x_back = (56 + 1) * 128: the descriptor starts one row and one pixel before the tensor
+            const unsigned base = (unsigned)((n * 56 + tr * 4) * 56) * 128u;
+            unsigned valid = ok_mask;
+            if (tr == 0) valid &= ~top_mask;
+            if (tr == 13) valid &= ~bot_mask;
+            char* dst = smem + W_BYTES + buf * X_BYTES + lw * 1024;
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+#if defined(C64_ABL) && C64_ABL == 2
+                const unsigned voff = kOobOffset | ((valid >> i) & (base + rel[i]) & 0u);
+#else
+                const unsigned voff = ((valid >> i) & 1u) ? base + rel[i] : kOobOffset;
+#endif
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void*)(dst + i * 4096), 16, voff, 0, 0, 0);
+            }
+        };
+        if (my_tiles > 0) issue(first, 0);
+        __syncthreads();                               // weights staged (all 8 waves)
+        for (int t = 0; t < my_tiles; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile t landed (nothing newer is in flight yet)
+            __builtin_amdgcn_s_barrier();                          // ... and the consumers are done with tile t-1
+            if (t + 1 < my_tiles) issue(first + (t + 1) * grid, (t + 1) & 1);
+        }
+    } else {
+        // =============================== consumer waves =============================================
+        const int wave_c = wave >> 1, wave_p = wave & 1;
+        const int fr = lane & 15, fq = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+        const int cout_lane = wave_c * 32 + 8 * fq;
+        const f32x4 b_lo = *reinterpret_cast<const f32x4*>(a.bias + cout_lane);
+        const f32x4 b_hi = *reinterpret_cast<const f32x4*>(a.bias + cout_lane + 4);
+        const int w_frag = (wave_c * 32 + fr) * 128 + ((fq ^ (fr & 7)) << 4);        // + tap*8192 + m*2048, ^64 for kk = 1
+        // B fragment addresses inside an input image, per pixel block j and column shift kw (kk = 0; kk = 1 is ^ 64)
+        int xa[7][3];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int p = wave_p * 112 + 16 * j + fr;
+            const int r = p / 56, c = p - r * 56;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) xa[j][kw] = (r * 58 + c + kw) * 128 + ((fq ^ ((c + kw) & 7)) << 4);
+        }
+        __syncthreads();                               // weights staged
+        for (int t = 0; t < my_tiles; ++t) {
+            __builtin_amdgcn_s_barrier();              // tile t has landed
+            const char* xb = smem + W_BYTES + (t & 1) * X_BYTES;
+            f32x4 acc[2][7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) { acc[0][j] = b_lo; acc[1][j] = b_hi; }
+            // 18 K-blocks (9 taps x 2 halves of 32 channels).  One wave per SIMD has nobody to hide LDS latency behind:
+            // the 9 fragment reads of block i+1 are issued before the 14 MFMAs of block i (explicit double buffer,
+            // order pinned with sched_group_barrier).
+            bf16x8 wf[2][2], xf[2][7];
+            auto read_block = [&](int it, bf16x8 (&w)[2], bf16x8 (&x)[7]) {
+                const int tap = it >> 1, kk = it & 1, kh = tap / 3, kw = tap - kh * 3;
+                const char* wt = smem + tap * 8192;
+                w[0] = *reinterpret_cast<const bf16x8*>(wt + (w_frag ^ (kk << 6)));
+                w[1] = *reinterpret_cast<const bf16x8*>(wt + 2048 + (w_frag ^ (kk << 6)));
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                    x[j] = *reinterpret_cast<const bf16x8*>(xb + kh * (58 * 128) + (xa[j][kw] ^ (kk << 6)));
+            };
+            read_block(0, wf[0], xf[0]);
+#pragma unroll
+            for (int it = 0; it < 18; ++it) {
+                if (it + 1 < 18) read_block(it + 1, wf[(it + 1) & 1], xf[(it + 1) & 1]);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[it & 1][0], xf[it & 1][j], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[it & 1][1], xf[it & 1][j], acc[1][j], 0, 0, 0);
+                }
+                if (it + 1 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
+            }
+            // ---- bias is in the accumulators; ReLU, bf16, 16-B stores
+            const int tile = first + t * grid;
+            const unsigned pix0 = (unsigned)(tile * 224 + wave_p * 112 + fr);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const f32x4 lo = acc[0][j], hi = acc[1][j];
+                u32x4 o = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                                  pack_bf16x2(hi[2], hi[3])};
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                }
+#if !(defined(C64_ABL) && C64_ABL == 3)
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_y, (pix0 + 16 * j) * 128u + cout_lane * 2, 0, 0);
+#else
+                if (o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_y, (pix0 + 16 * j) * 128u + cout_lane * 2, 0, 0);
+#endif
+            }
+        }
+    }
+#else
+    (void)a;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Bottleneck tail (layer1): conv3 1x1 (64 -> 256) + bn3 + identity + ReLU, and the NEXT block's
 // conv1 1x1 (256 -> C1) + bn1 + ReLU, in one pass over the pixels.
 // Why: at 56x56 these two layers are HBM-bound (the block output is 2*M*256 bytes, written by conv3 and read

@@ -283,7 +283,30 @@ hipError_t launch_igemm_ws_t(ConvArgs a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// layer1 conv2 shape (3x3 s1 p1, 64 -> 64, 56x56): filter bank resident in LDS (kernels.h: conv3x3_c64_kernel); tile id 64+16
+constexpr int kTileC64 = kWsBit | 16;
+bool is_c64_shape(const ConvArgs& a) {
+    return a.ks == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 64 && a.Cout == 64 && a.H == 56 && a.W == 56 && a.res == nullptr &&
+           a.x_cstride == 64 && a.y_cstride == 64;
+}
+hipError_t launch_conv3x3_c64(const ConvArgs& a, hipStream_t s) {
+    if (!is_c64_shape(a)) return hipErrorInvalidValue;
+    constexpr size_t lds = 9 * 64 * 128 + 2 * 352 * 128;      // 163,840 = all of the CU's LDS
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        g_num_cus = prop.multiProcessorCount;
+    }
+    const int tiles = a.N * 14;
+    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(tiles < g_num_cus ? tiles : g_num_cus), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 int auto_tile(const ConvArgs& a) {
+    if (is_c64_shape(a)) return kTileC64;
     if (a.N >= 48 && a.H == a.W)
         for (const TunedTile& t : kTuned)
             if (t.h == a.H && t.cin == a.Cin && t.cout == a.Cout && t.ks == a.ks && t.stride == a.stride &&
@@ -301,6 +324,7 @@ hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s, bool split =
     }
     if (tile == 0) tile = auto_tile(a);
     const bool pers = (tile & kPersistBit) != 0;
+    if (tile == kTileC64) return launch_conv3x3_c64(a, s);
     if (tile & kWsBit) {
         // <couts, pixels, consumer waves (couts x pixels), loader waves, LDS stages>
         switch (tile & (kPersistBit - 1)) {

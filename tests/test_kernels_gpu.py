@@ -52,6 +52,8 @@ CONV_CASES = [
     (1, 1, 1, 64, 64, 3, 1, 1, True, False),       # single pixel: every tap but the centre is padding
     (3, 5, 9, 128, 256, 3, 1, 1, True, True),      # non-square, 3 images: halo rows cross image borders
     (2, 14, 14, 256, 256, 3, 1, 1, True, False),
+    (3, 56, 56, 64, 64, 3, 1, 1, True, False),     # layer1 conv2: resident-weights kernel (TILE_C64); 42 tiles, image borders
+    (1, 56, 56, 64, 64, 3, 1, 1, False, False),
 ]
 
 
@@ -89,7 +91,10 @@ def test_conv2d_matches_oracle(lib_built, case):
     wd = wt.permute(0, 2, 3, 1).contiguous().to(d)
     bd = bias.to(d)
     rd = res.permute(0, 2, 3, 1).contiguous().to(d) if has_res else None
-    for tile in _tiles_for(cout):
+    tiles = _tiles_for(cout)
+    if (h, w, cin, cout, k, stride, pad, has_res) == (56, 56, 64, 64, 3, 1, 1, False):
+        tiles = tiles + [ops.TILE_C64]
+    for tile in tiles:
         # guard band behind the result: the tile rows past M (ragged last tile) must not be stored anywhere
         numel = n * ho * wo * cout
         buf = torch.full((numel + 512 * cout,), -7.0, dtype=torch.bfloat16, device=d)
