@@ -252,11 +252,11 @@ hipError_t launch_igemm_t(ConvArgs a, bool persistent, hipStream_t s) {
 struct TunedTile { int h, cin, cout, ks, stride, res, tile; };
 constexpr TunedTile kTuned[] = {
     {56, 64, 64, 1, 1, 0, 73},    {56, 64, 64, 3, 1, 0, 2},     {56, 64, 256, 1, 1, 1, 72},   {56, 64, 256, 1, 1, 0, 38},
-    {56, 256, 64, 1, 1, 0, 73},    {56, 256, 128, 1, 1, 0, 40},  {56, 128, 128, 3, 2, 0, 1},   {28, 128, 512, 1, 1, 1, 72},
-    {56, 256, 512, 1, 2, 0, 42},  {28, 512, 128, 1, 1, 0, 65},   {28, 128, 128, 3, 1, 0, 33},  {28, 512, 256, 1, 1, 0, 43},
-    {28, 256, 256, 3, 2, 0, 44},  {14, 256, 1024, 1, 1, 1, 43}, {28, 512, 1024, 1, 2, 0, 43}, {14, 1024, 256, 1, 1, 0, 44},
-    {14, 256, 256, 3, 1, 0, 44},  {14, 1024, 512, 1, 1, 0, 43}, {14, 512, 512, 3, 2, 0, 33},  {7, 512, 2048, 1, 1, 1, 43},
-    {14, 1024, 2048, 1, 2, 0, 43}, {7, 2048, 512, 1, 1, 0, 68}, {7, 512, 512, 3, 1, 0, 68},
+    {56, 256, 64, 1, 1, 0, 73},    {56, 256, 128, 1, 1, 0, 40},  {56, 128, 128, 3, 2, 0, 65},   {28, 128, 512, 1, 1, 1, 72},
+    {56, 256, 512, 1, 2, 0, 42},  {28, 512, 128, 1, 1, 0, 65},   {28, 128, 128, 3, 1, 0, 72},  {28, 512, 256, 1, 1, 0, 72},
+    {28, 256, 256, 3, 2, 0, 44},  {14, 256, 1024, 1, 1, 1, 72}, {28, 512, 1024, 1, 2, 0, 72}, {14, 1024, 256, 1, 1, 0, 44},
+    {14, 256, 256, 3, 1, 0, 68},  {14, 1024, 512, 1, 1, 0, 72}, {14, 512, 512, 3, 2, 0, 68},  {7, 512, 2048, 1, 1, 1, 43},
+    {14, 1024, 2048, 1, 2, 0, 43}, {7, 2048, 512, 1, 1, 0, 72}, {7, 512, 512, 3, 1, 0, 68},
 };
 
 // Role-specialised kernel (loader waves + consumer waves), always one persistent workgroup per CU: tile id + 64
