@@ -33,6 +33,7 @@ import torch  # noqa: E402
 BATCH = 256
 GFLOP_PER_FRAME = 8.174272512          # 2 x 4,087,136,256 MAC, 53 convs
 MFMA_BF16_PEAK_TFLOPS = 2500.0         # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0                  # HBM3E, same guide
 HBM_PEAK_GBS = 8000.0
 
 
@@ -187,7 +188,7 @@ def main() -> None:
                 traffic = json.loads(tpath.read_text())["igemm"]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": "igemm_bf16_kernel + igemm_ws_kernel (%d conv launches/step)" % round(ig["launches"] / max(1, args.steps)), "achieved": achieved,
+        roofline = {"bound": "mfma", "kernel": "igemm_bf16_kernel + igemm_ws_kernel + conv3x3_c64_kernel (%d conv launches/step)" % round(ig["launches"] / max(1, args.steps)), "achieved": achieved,
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
                     "traffic": traffic,
                     "traffic_note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch, batch 256, from "
@@ -196,6 +197,18 @@ def main() -> None:
                     "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
                     "flops_per_launch": ig["flops"] / max(1, ig["launches"]),
                     "layerwise_GBps": ig["bytes"] / (ig["ms"] * 1e-3) / 1e9 if ig["ms"] > 0 else 0.0}
+        tl = prof.get("bneck_tail")
+        if tl and tl["ms"] > 0:       # second kernel family by time: the fused bottleneck tails are HBM-bound
+            t_traffic = None
+            try:
+                t_traffic = json.loads(tpath.read_text())["bneck_tail"]["hbm_bytes_per_launch"]
+            except Exception:
+                pass
+            t_ach = tl["bytes"] / (tl["ms"] * 1e-3) / 1e9
+            roofline["second_kernel"] = {"kernel": "bneck_tail_kernel / bneck_tail2_kernel (%d launches/step)" % round(tl["launches"] / max(1, args.steps)),
+                                         "bound": "hbm", "achieved": t_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": t_ach / HBM_PEAK_GBPS,
+                                         "traffic": t_traffic, "avg_launch_us": 1e3 * tl["ms"] / max(1, tl["launches"]),
+                                         "bytes_per_launch": tl["bytes"] / max(1, tl["launches"])}
         classes = ("igemm", "bneck_tail", "conv1", "maxpool", "avgpool", "stem_pack")
         tot_ms = sum(prof[k]["ms"] for k in classes)
         kernels = {k: {"launches_per_step": prof[k]["launches"] / args.steps, "ms_per_step": prof[k]["ms"] / args.steps,
