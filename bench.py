@@ -87,8 +87,9 @@ def main() -> None:
     ap.add_argument("--streams", type=int, default=0, help="internal streams the batch is split over (0 = library default)")
     ap.add_argument("--precision", choices=["bf16", "fp32x"], default="bf16",
                     help="bf16 = headline path; fp32x = fp32-class accuracy mode (bf16 head/tail pairs, 3 products per conv)")
-    ap.add_argument("--input", choices=["f32", "u8"], default="f32",
-                    help="f32 = the reference boundary (normalised fp32 NCHW frames); u8 = resized uint8 crops, normalised in the stem kernel")
+    ap.add_argument("--input", choices=["f32", "u8", "video"], default="f32",
+                    help="f32 = the reference boundary (normalised fp32 NCHW frames); u8 = resized uint8 crops, normalised in the stem "
+                         "kernel; video = decoded 1002x1000 uint8 HWC frames + a 500-pixel crop box: crop + bilinear resize on the device too")
     ap.add_argument("--no-fused-stem", action="store_true", help="A/B: run conv1 / maxpool as separate kernels")
     ap.add_argument("--no-fuse-tail", action="store_true", help="A/B: layer1 conv3 and the next conv1 as two igemm launches")
     ap.add_argument("--no-overlap-ds", action="store_true", help="A/B: downsample convs on the main stream")
@@ -138,6 +139,14 @@ def main() -> None:
         g = torch.Generator().manual_seed(1234 + rank)
         x = torch.randint(0, 256, (args.batch, 3, 224, 224), generator=g, dtype=torch.uint8).to(dev)
         run = bb.features_u8
+    if args.input == "video":          # what the video decoder hands over (H36M frames are 1002x1000): 3 MB per frame
+        from implementation_phd_lab_vision_amd.frames import crop_and_resize_video_uint8
+        g = torch.Generator().manual_seed(1234 + rank)
+        x = torch.randint(0, 256, (args.batch, 1002, 1000, 3), generator=g, dtype=torch.uint8).to(dev)
+        box = [251, 250, 500, 500]
+
+        def run(frames, out=None):
+            return bb.features_u8(crop_and_resize_video_uint8(frames, box), out=out)
     feats = torch.empty((args.batch, 2048), dtype=torch.float32, device=dev)
     gathered = [torch.empty_like(feats) for _ in range(world)] if (dist is not None and rank == 0) else None
 

@@ -143,6 +143,13 @@ class ResNet50Backbone:
         _lib.check(lib.r50_forward_u8(self._handle, x_u8.data_ptr(), n, out.data_ptr(), stream), self._handle, "r50_forward_u8")
         return out
 
+    def features_from_video(self, frames_thwc_u8: torch.Tensor, box, mode: int = 0) -> torch.Tensor:
+        """Decoded clip in, features out: ``(T,H,W,3)`` uint8 frames on the device + crop box ``[top,left,hh,ww]``
+        (``frames.square_crop_from_2d``) -> crop + bilinear resize on the device (``frames.crop_and_resize_video_uint8``,
+        src/dataset.py:141-149) -> ``/255``, ``Normalize`` and the backbone (``features_u8``) -> (T,2048) fp32."""
+        from .frames import crop_and_resize_video_uint8
+        return self.features_u8(crop_and_resize_video_uint8(frames_thwc_u8, box, 224, mode))
+
     def layer(self, x: torch.Tensor, name: str) -> torch.Tensor:
         """Debug hook: named intermediate activation, NHWC (per-layer parity tests).  bf16 tensor in bf16
         mode; in fp32x mode the (head, tail) pair is recombined into an fp32 tensor."""

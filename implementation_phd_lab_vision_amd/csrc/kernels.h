@@ -1201,6 +1201,78 @@ __global__ __launch_bounds__(512) void bneck_tail2_kernel(const Tail2Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Frame producer: crop box + bilinear resize of decoded uint8 frames, on the device.
+// Reference: _crop_and_resize_video_uint8 (src/dataset.py:141-149) = slice [top:top+hh, left:left+ww] of the
+// (T,H,W,3) clip, then torchvision resize(..., [224,224], antialias=False) on uint8, which on an AVX2 CPU is ATen's
+// native uint8 bilinear kernel: separable, horizontal pass first, int16 fixed-point weights, uint8 intermediate
+// (oracle/resize_oracle.py restates it and is pinned against torch itself).  Same integer arithmetic here, both
+// passes in one thread: 2x2 source pixels -> two horizontally resampled uint8 values -> one output value.
+// The reference itself imports the v1 API (`torchvision.transforms.functional.resize`), which converts uint8 to fp32,
+// interpolates and rounds: `float_mode` does that (fp32 lambdas from the host, round half to even).  The CPU kernel's
+// FMA contraction is a property of the torch build, so that mode matches torch here on all but ~5e-6 of the bytes
+// (1 LSB at rounding ties); the fixed-point mode is bit-exact.
+// Tables (host-built in double exactly as ATen does, r50_abi.hip): per output column [first source column, w0, w1],
+// per output row likewise; a border tap has w1 = 0.  Output is NCHW uint8, the layout r50_forward_u8 takes.
+// ------------------------------------------------------------------------------------------------
+struct ResizeArgs {
+    const unsigned char* src;   // (T, H, W, 3)
+    unsigned char* dst;         // (T, 3, out, out)
+    const int* tab;             // [xmin | xw0 | xw1 | ymin | yw0 | yw1], `out` ints each (float mode: w = fp32 lambda bits)
+    int T, H, W, top, left, hh, ww, out;
+    int px, py;                 // weight precisions (bits) of the horizontal / vertical pass (fixed-point mode)
+    int float_mode;             // 1: fp32 arithmetic + round-half-even (torchvision v1 `functional.resize` on uint8)
+};
+
+__global__ __launch_bounds__(256) void crop_resize_u8_kernel(const ResizeArgs a) {
+    const int quads = a.out >> 2;                                   // 4 output columns per thread
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int per_frame = a.out * quads;
+    if (idx >= a.T * per_frame) return;
+    const int t = idx / per_frame, r = idx - t * per_frame;
+    const int yo = r / quads, xq = r - yo * quads;
+    const int* xmin = a.tab, *xw0 = a.tab + a.out, *xw1 = a.tab + 2 * a.out;
+    const int* ymin = a.tab + 3 * a.out, *yw0 = a.tab + 4 * a.out, *yw1 = a.tab + 5 * a.out;
+    const int y0 = ymin[yo], y1 = min(y0 + 1, a.hh - 1);
+    const int wy0 = yw0[yo], wy1 = yw1[yo];
+    const unsigned char* f = a.src + (size_t)t * a.H * a.W * 3;
+    const unsigned char* row0 = f + ((size_t)(a.top + y0) * a.W + a.left) * 3;
+    const unsigned char* row1 = f + ((size_t)(a.top + y1) * a.W + a.left) * 3;
+    const int rx = 1 << (a.px - 1), ry = 1 << (a.py - 1);
+    unsigned out_c[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int xo = xq * 4 + q;
+        const int x0 = xmin[xo], x1 = min(x0 + 1, a.ww - 1);       // float mode: same second index (index0 + (index0 < size-1))
+        const int wx0 = xw0[xo], wx1 = xw1[xo];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int v;
+            if (a.float_mode) {
+                // ATen cpu_upsample_linear_channels_last: out = p00*w00 + p01*w01 + p10*w10 + p11*w11 with w_ij = h_i * w_j
+                // (fp32; the CPU build contracts some of it into FMAs -- this association is the closest match found)
+                const float lx0 = __int_as_float(wx0), lx1 = __int_as_float(wx1), ly0 = __int_as_float(wy0), ly1 = __int_as_float(wy1);
+                const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+                const float p00 = (float)row0[x0 * 3 + c], p01 = (float)row0[x1 * 3 + c];
+                const float p10 = (float)row1[x0 * 3 + c], p11 = (float)row1[x1 * 3 + c];
+                const float s0 = __fmaf_rn(p01, w01, p00 * w00), s1 = __fmaf_rn(p11, w11, p10 * w10);
+                v = (int)rintf(s0 + s1);                                    // torch.round = half to even; then .to(uint8)
+            } else {
+                int h0 = (wx0 * (int)row0[x0 * 3 + c] + wx1 * (int)row0[x1 * 3 + c] + rx) >> a.px;
+                int h1 = (wx0 * (int)row1[x0 * 3 + c] + wx1 * (int)row1[x1 * 3 + c] + rx) >> a.px;
+                h0 = min(max(h0, 0), 255); h1 = min(max(h1, 0), 255);        // the uint8 intermediate image
+                v = (wy0 * h0 + wy1 * h1 + ry) >> a.py;
+            }
+            v = min(max(v, 0), 255);
+            out_c[c] |= (unsigned)v << (8 * q);
+        }
+    }
+    const size_t plane = (size_t)a.out * a.out;
+    unsigned char* o = a.dst + (size_t)t * 3 * plane + (size_t)yo * a.out + xq * 4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<unsigned*>(o + c * plane) = out_c[c];
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stem, step 1: fp32 NCHW (N,3,224,224) -> bf16 "NHWC4" with a zero border:
 //   xp[n][hp][wp][4], hp = hi + 3 in [0,230), wp = wi + 4 in [0,232); channel 3 = 0.
 // One thread per output pixel (8 B).  The border is rewritten every call.

@@ -148,6 +148,21 @@ int r50_op_bneck_tail(const void* y2_bf16, int64_t m, int cmid, const void* w3_b
                       const void* identity_bf16, const void* wd_bf16, const float* bd, void* out_bf16, const void* w1_bf16,
                       int c1, const float* b1, void* y1n_bf16, void* stream);
 
+/* Frame producer, the step before the path: crop box + bilinear resize of a decoded clip on the
+ * device.  Replaces `_crop_and_resize_video_uint8` (src/dataset.py:141-149) up to, not including, the `/255`:
+ * frames (t,h,w,3) uint8 HWC as the video decoder returns them -> `frames[:, top:top+hh, left:left+ww]` ->
+ * resize to (out_size,out_size), bilinear, no antialias -> out (t,3,out_size,out_size) uint8 NCHW, the input of
+ * r50_forward_u8.  mode R50_RESIZE_FLOAT: the arithmetic of `torchvision.transforms.functional.resize` (the v1 API
+ * the reference imports, :13): uint8 -> fp32, ATen bilinear (align_corners=False), round half to even, uint8.
+ * mode R50_RESIZE_FIXED: ATen's native uint8 kernel (what the v2 API runs on an AVX2 CPU): two-pass int16 fixed
+ * point with a uint8 intermediate, bit-exact.  The box comes from `_compute_square_crop_from_2d` (:75-104; host
+ * code, mirrored in frames.py) and must lie inside the frame; out_size % 4 == 0.  Device pointers; the
+ * index / weight tables are built on the host. */
+#define R50_RESIZE_FLOAT 0
+#define R50_RESIZE_FIXED 1
+int r50_op_crop_resize_u8(const void* frames_thwc_u8, int t, int h, int w, int top, int left, int hh, int ww,
+                          void* out_tchw_u8, int out_size, int mode, void* stream);
+
 /* AdaptiveAvgPool2d((1,1)) + flatten(1): (n,hw,c) bf16 -> (n,c) fp32; c % 8 == 0. */
 int r50_op_avgpool(const void* x_nhwc_bf16, int n, int hw, int c, float* y_f32, void* stream);
 
