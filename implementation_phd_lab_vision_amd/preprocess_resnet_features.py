@@ -107,11 +107,27 @@ def _resolve_device(name: str, ctx: D.RankContext) -> torch.device:
     return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
 
 
-def extract_features(backbone: Callable[[torch.Tensor], torch.Tensor], variants_batch, device: torch.device) -> torch.Tensor:
+def _is_time_reverse_of(video_rev: torch.Tensor, video: torch.Tensor) -> bool:
+    """True if ``video_rev`` (B,T,3,224,224) is ``video`` flipped along T -- checked on the first and the last frame
+    of every clip (host tensors, a few MB)."""
+    return video_rev.shape == video.shape and torch.equal(video_rev[:, 0], video[:, -1]) and torch.equal(video_rev[:, -1], video[:, 0])
+
+
+def extract_features(backbone: Callable[[torch.Tensor], torch.Tensor], variants_batch, device: torch.device,
+                     reuse_trev: bool = True) -> torch.Tensor:
     """The hot call site (:287-297): every variant's (B,T,3,224,224) clip batch -> (B,T,2048) fp32.
-    Returns (B, V, T, 2048) on ``device``."""
+    Returns (B, V, T, 2048) on ``device``.
+
+    The backbone is a per-frame function, so the features of the temporal-reverse variant (``AUG_NAMES[3]``, built
+    by ``_aug_temporal_reverse`` from the same clip as variant 0: src/dataset.py:199-207,424-426) are the
+    features of variant 0 in reverse frame order, bit for bit: under ``--augment`` that forward pass (a quarter of
+    the work) is replaced by a flip.  Only when the frames really are the reverse (checked per batch)."""
     per_variant = []
-    for v_video, *_ in variants_batch:
+    for vi, (v_video, *_rest) in enumerate(variants_batch):
+        if (reuse_trev and len(variants_batch) == len(AUG_NAMES) and vi == AUG_NAMES.index("trev")
+                and _is_time_reverse_of(v_video, variants_batch[0][0])):
+            per_variant.append(per_variant[0].flip(1))
+            continue
         v_video = v_video.to(device, non_blocking=True)
         b, t, c, h, w = v_video.shape
         x = v_video.view(b * t, c, h, w).contiguous()

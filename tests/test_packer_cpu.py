@@ -118,3 +118,33 @@ def test_collate_variants_matches_reference_layout():
     assert len(out) == 4 and all(len(v) == 4 for v in out)
     assert out[0][0].shape == (3, 2, 3, 224, 224) and out[2][3].shape == (3, 3, 3)
     assert torch.equal(out[3][0][1], ds[1][3][0])
+
+
+def test_trev_variant_reuses_orig_features():
+    """Under --augment the temporal-reverse variant's features are variant 0's in reverse frame order: the CLI skips
+    that forward pass.  Same result as running it, and the backbone sees 3 of the 4 variants; a 4th variant that is
+    NOT the time reverse is still computed."""
+    import torch
+    from implementation_phd_lab_vision_amd.preprocess_resnet_features import extract_features, collate_variants
+    from implementation_phd_lab_vision_amd.synthetic import SyntheticClips
+
+    calls = []
+
+    def backbone(x):                                  # per-frame function of the pixels, (N,3,224,224) -> (N,2048,1,1)
+        calls.append(x.shape[0])
+        j = torch.arange(2048)
+        return x[:, j % 3, (j // 3) % 224, (j * 7) % 224].reshape(x.shape[0], 2048, 1, 1)
+
+    ds = SyntheticClips(2, seq_len=3, augment=True)
+    batch = collate_variants([ds[0], ds[1]])
+    full = extract_features(backbone, batch, torch.device("cpu"), reuse_trev=False)
+    n_full = len(calls)
+    calls.clear()
+    fast = extract_features(backbone, batch, torch.device("cpu"))
+    assert n_full == 4 and len(calls) == 3
+    assert torch.equal(full, fast)
+    broken = [tuple(v) for v in batch]
+    broken[3] = (broken[3][0].clone() + 1.0,) + tuple(broken[3][1:])
+    calls.clear()
+    extract_features(backbone, broken, torch.device("cpu"))
+    assert len(calls) == 4
