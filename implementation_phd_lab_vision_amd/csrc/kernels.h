@@ -1211,17 +1211,64 @@ __global__ __launch_bounds__(512) void bneck_tail2_kernel(const Tail2Args a) {
 // interpolates and rounds: `float_mode` does that (fp32 lambdas from the host, round half to even).  The CPU kernel's
 // FMA contraction is a property of the torch build, so that mode matches torch here on all but ~5e-6 of the bytes
 // (1 LSB at rounding ties); the fixed-point mode is bit-exact.
-// Tables (host-built in double exactly as ATen does, r50_abi.hip): per output column [first source column, w0, w1],
-// per output row likewise; a border tap has w1 = 0.  Output is NCHW uint8, the layout r50_forward_u8 takes.
+// Per output column / row: first source index and two tap weights (a border tap has w1 = 0), computed in the kernel;
+// only the fixed-point precisions (a maximum over all weights of an axis) come from the host.  Fully asynchronous on
+// the stream.  Output is NCHW uint8, the layout r50_forward_u8 takes.
 // ------------------------------------------------------------------------------------------------
 struct ResizeArgs {
     const unsigned char* src;   // (T, H, W, 3)
     unsigned char* dst;         // (T, 3, out, out)
-    const int* tab;             // [xmin | xw0 | xw1 | ymin | yw0 | yw1], `out` ints each (float mode: w = fp32 lambda bits)
     int T, H, W, top, left, hh, ww, out;
-    int px, py;                 // weight precisions (bits) of the horizontal / vertical pass (fixed-point mode)
+    int px, py;                 // weight precisions (bits) of the horizontal / vertical pass (fixed-point mode; host-computed)
     int float_mode;             // 1: fp32 arithmetic + round-half-even (torchvision v1 `functional.resize` on uint8)
 };
+
+// Source index and the two tap weights of output index i along one axis, computed per thread with the very
+// operations the host-side restatement uses (IEEE, no contraction: the library is built with -ffp-contract=off).
+// Fixed-point mode: ATen `_compute_indices_min_size_weights` in double, scaled to `prec` bits; float mode:
+// `area_pixel_compute_source_index` / `guard_index_and_lambda` in fp32 with the index expression as one fma.
+__device__ __forceinline__ void resize_taps(int i, int in_size, int out_size, int prec, bool float_mode, int& i0, int& w0, int& w1) {
+    if (float_mode) {
+        float l0 = 1.0f, l1 = 0.0f;
+        int idx = i;
+        if (in_size != out_size) {
+            const float scale = (float)in_size / (float)out_size;
+            float real = __fmaf_rn(scale, (float)i + 0.5f, -0.5f);
+            if (real < 0.0f) real = 0.0f;
+            idx = (int)floorf(real);
+            if (idx > in_size - 1) idx = in_size - 1;
+            l1 = real - (float)idx;
+            l1 = l1 < 0.0f ? 0.0f : (l1 > 1.0f ? 1.0f : l1);
+            l0 = 1.0f - l1;
+        }
+        i0 = idx; w0 = __float_as_int(l0); w1 = __float_as_int(l1);
+    } else {
+        const double scale = (double)in_size / (double)out_size;
+        double real = scale * ((double)i + 0.5) - 0.5;
+        if (real < 0.0) real = 0.0;
+        long idx = (long)floor(real);
+        if (idx > in_size - 1) idx = in_size - 1;
+        double lam = real - (double)idx;
+        lam = lam < 0.0 ? 0.0 : (lam > 1.0 ? 1.0 : lam);
+        const long umin = idx, umax = idx + 2;                      // support = 1
+        const long lo = umin > 0 ? umin : 0;
+        const long size = (umax < in_size ? umax : in_size) - lo;
+        double w[2] = {0.0, 0.0};
+        long w_index = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double x = fabs((double)j - lam);
+            const double wj = x < 1.0 ? 1.0 - x : 0.0;
+            if (umin + j <= 0) w_index = 0;
+            else if (umin + j >= in_size - 1) w_index = size - 1;
+            if (w_index == 0) w[0] += wj; else w[1] += wj;
+            ++w_index;
+        }
+        i0 = (int)lo;
+        w0 = (int)(0.5 + w[0] * (double)(1 << prec));
+        w1 = (int)(0.5 + w[1] * (double)(1 << prec));
+    }
+}
 
 __global__ __launch_bounds__(256) void crop_resize_u8_kernel(const ResizeArgs a) {
     const int quads = a.out >> 2;                                   // 4 output columns per thread
@@ -1230,10 +1277,9 @@ __global__ __launch_bounds__(256) void crop_resize_u8_kernel(const ResizeArgs a)
     if (idx >= a.T * per_frame) return;
     const int t = idx / per_frame, r = idx - t * per_frame;
     const int yo = r / quads, xq = r - yo * quads;
-    const int* xmin = a.tab, *xw0 = a.tab + a.out, *xw1 = a.tab + 2 * a.out;
-    const int* ymin = a.tab + 3 * a.out, *yw0 = a.tab + 4 * a.out, *yw1 = a.tab + 5 * a.out;
-    const int y0 = ymin[yo], y1 = min(y0 + 1, a.hh - 1);
-    const int wy0 = yw0[yo], wy1 = yw1[yo];
+    int y0, wy0, wy1;
+    resize_taps(yo, a.hh, a.out, a.py, a.float_mode != 0, y0, wy0, wy1);
+    const int y1 = min(y0 + 1, a.hh - 1);
     const unsigned char* f = a.src + (size_t)t * a.H * a.W * 3;
     const unsigned char* row0 = f + ((size_t)(a.top + y0) * a.W + a.left) * 3;
     const unsigned char* row1 = f + ((size_t)(a.top + y1) * a.W + a.left) * 3;
@@ -1242,8 +1288,9 @@ __global__ __launch_bounds__(256) void crop_resize_u8_kernel(const ResizeArgs a)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int xo = xq * 4 + q;
-        const int x0 = xmin[xo], x1 = min(x0 + 1, a.ww - 1);       // float mode: same second index (index0 + (index0 < size-1))
-        const int wx0 = xw0[xo], wx1 = xw1[xo];
+        int x0, wx0, wx1;
+        resize_taps(xo, a.ww, a.out, a.px, a.float_mode != 0, x0, wx0, wx1);
+        const int x1 = min(x0 + 1, a.ww - 1);                       // float mode: same second index (index0 + (index0 < size-1))
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             int v;

@@ -1056,12 +1056,13 @@ int r50_op_bneck_tail(const void* y2, int64_t m, int cmid, const void* w3, const
     return R50_OK;
 }
 
-// ATen's index / weight computation for the native uint8 bilinear resize (antialias off), in double, then int16 fixed
-// point: aten/src/ATen/native/cpu/UpSampleKernel.cpp `_compute_indices_min_size_weights` +
-// `_compute_index_ranges_int16_weights` (restated in oracle/resize_oracle.py:index_weights_int16).
-static int build_resize_table(int in_size, int out_size, int* idx_min, int* w0, int* w1) {
+// Weight precision of ATen's native uint8 bilinear resize (antialias off) along one axis: the largest p with
+// round(max_weight * 2^(p+1)) < 2^15, the maximum taken over every tap weight of the axis
+// (aten/src/ATen/native/cpu/UpSampleKernel.cpp `_compute_index_ranges_int16_weights`; weights as in
+// `_compute_indices_min_size_weights`, restated in oracle/resize_oracle.py:index_weights_int16 and, per thread, in
+// kernels.h:resize_taps).
+static int resize_weight_precision(int in_size, int out_size) {
     const double scale = (double)in_size / (double)out_size;
-    std::vector<double> wa(out_size), wb(out_size);
     double wt_max = 0.0;
     for (int i = 0; i < out_size; ++i) {
         double real = scale * (i + 0.5) - 0.5;
@@ -1070,53 +1071,26 @@ static int build_resize_table(int in_size, int out_size, int* idx_min, int* w0, 
         if (idx > in_size - 1) idx = in_size - 1;
         double lam = real - (double)idx;
         lam = lam < 0.0 ? 0.0 : (lam > 1.0 ? 1.0 : lam);
-        const long umin = idx, umax = idx + 2;                      // support = 1
+        const long umin = idx, umax = idx + 2;
         const long lo = umin > 0 ? umin : 0;
         const long size = (umax < in_size ? umax : in_size) - lo;
         double w[2] = {0.0, 0.0};
         long w_index = 0;
         for (int j = 0; j < 2; ++j) {
-            double x = std::fabs((double)j - lam);
+            const double x = std::fabs((double)j - lam);
             const double wj = x < 1.0 ? 1.0 - x : 0.0;
             if (umin + j <= 0) w_index = 0;
             else if (umin + j >= in_size - 1) w_index = size - 1;
-            w[w_index] += wj;
+            if (w_index == 0) w[0] += wj; else w[1] += wj;
             ++w_index;
         }
-        idx_min[i] = (int)lo; wa[i] = w[0]; wb[i] = w[1];
         if (w[0] > wt_max) wt_max = w[0];
         if (w[1] > wt_max) wt_max = w[1];
     }
     int precision = 0;
     for (; precision < 22; ++precision)
         if ((int)(0.5 + wt_max * (double)(1 << (precision + 1))) >= (1 << 15)) break;
-    for (int i = 0; i < out_size; ++i) {
-        w0[i] = (int)(0.5 + wa[i] * (double)(1 << precision));
-        w1[i] = (int)(0.5 + wb[i] * (double)(1 << precision));
-    }
     return precision;
-}
-
-// fp32 source index / lambda of ATen's float bilinear kernels (UpSample.h: area_pixel_compute_source_index,
-// guard_index_and_lambda, compute_source_index_and_lambda); the index expression as one fma, like the CPU build.
-static void build_resize_table_f32(int in_size, int out_size, int* idx_min, int* w0, int* w1) {
-    const float scale = (float)in_size / (float)out_size;
-    for (int i = 0; i < out_size; ++i) {
-        float l0 = 1.0f, l1 = 0.0f;
-        long idx = i;
-        if (in_size != out_size) {
-            float real = std::fmaf(scale, (float)i + 0.5f, -0.5f);
-            if (real < 0.0f) real = 0.0f;
-            idx = (long)std::floor(real);
-            if (idx > in_size - 1) idx = in_size - 1;
-            l1 = real - (float)idx;
-            l1 = l1 < 0.0f ? 0.0f : (l1 > 1.0f ? 1.0f : l1);
-            l0 = 1.0f - l1;
-        }
-        idx_min[i] = (int)idx;
-        std::memcpy(&w0[i], &l0, 4);
-        std::memcpy(&w1[i], &l1, 4);
-    }
 }
 
 int r50_op_crop_resize_u8(const void* frames, int t, int h, int w, int top, int left, int hh, int ww, void* out, int out_size,
@@ -1124,32 +1098,21 @@ int r50_op_crop_resize_u8(const void* frames, int t, int h, int w, int top, int 
     if (!frames || !out || t < 1 || h < 1 || w < 1 || hh < 1 || ww < 1 || top < 0 || left < 0 || top + hh > h || left + ww > w ||
         out_size < 4 || (out_size & 3) || out_size > 4096 || (long long)t * h * w * 3 >= (1ll << 40))
         return fail(nullptr, R50_ERR_INVALID, "r50_op_crop_resize_u8: invalid arguments (the box must lie inside the frame; out_size % 4 == 0)");
-    hipStream_t s = (hipStream_t)stream;
-    std::vector<int> tab(6 * (size_t)out_size);
-    ResizeArgs a;
     if (mode != R50_RESIZE_FLOAT && mode != R50_RESIZE_FIXED) return fail(nullptr, R50_ERR_INVALID, "r50_op_crop_resize_u8: unknown mode");
+    ResizeArgs a;
     a.float_mode = (mode == R50_RESIZE_FLOAT);
     a.px = a.py = 1;
-    if (a.float_mode) {
-        build_resize_table_f32(ww, out_size, &tab[0], &tab[out_size], &tab[2 * out_size]);
-        build_resize_table_f32(hh, out_size, &tab[3 * out_size], &tab[4 * out_size], &tab[5 * out_size]);
-    } else {
-        a.px = build_resize_table(ww, out_size, &tab[0], &tab[out_size], &tab[2 * out_size]);
-        a.py = build_resize_table(hh, out_size, &tab[3 * out_size], &tab[4 * out_size], &tab[5 * out_size]);
+    if (!a.float_mode) {
+        a.px = resize_weight_precision(ww, out_size);
+        a.py = resize_weight_precision(hh, out_size);
         if (a.px < 1 || a.py < 1) return fail(nullptr, R50_ERR_INVALID, "r50_op_crop_resize_u8: degenerate weights");
     }
-    int* dtab = nullptr;
-    HIP_TRY(nullptr, hipMallocAsync((void**)&dtab, tab.size() * sizeof(int), s));
-    HIP_TRY(nullptr, hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_TRY(nullptr, hipStreamSynchronize(s));            // `tab` is a host temporary (pageable copy)
-    a.src = (const unsigned char*)frames; a.dst = (unsigned char*)out; a.tab = dtab;
+    a.src = (const unsigned char*)frames; a.dst = (unsigned char*)out;
     a.T = t; a.H = h; a.W = w; a.top = top; a.left = left; a.hh = hh; a.ww = ww; a.out = out_size;
     const long long threads = (long long)t * out_size * (out_size / 4);
-    hipLaunchKernelGGL(crop_resize_u8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(crop_resize_u8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
-    hipError_t e2 = hipFreeAsync(dtab, s);
-    if (e != hipSuccess || e2 != hipSuccess)
-        return fail(nullptr, R50_ERR_HIP, std::string("r50_op_crop_resize_u8: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    if (e != hipSuccess) return fail(nullptr, R50_ERR_HIP, std::string("r50_op_crop_resize_u8: ") + hipGetErrorString(e));
     return R50_OK;
 }
 

@@ -156,8 +156,8 @@ int r50_op_bneck_tail(const void* y2_bf16, int64_t m, int cmid, const void* w3_b
  * the reference imports, :13): uint8 -> fp32, ATen bilinear (align_corners=False), round half to even, uint8.
  * mode R50_RESIZE_FIXED: ATen's native uint8 kernel (what the v2 API runs on an AVX2 CPU): two-pass int16 fixed
  * point with a uint8 intermediate, bit-exact.  The box comes from `_compute_square_crop_from_2d` (:75-104; host
- * code, mirrored in frames.py) and must lie inside the frame; out_size % 4 == 0.  Device pointers; the
- * index / weight tables are built on the host. */
+ * code, mirrored in frames.py) and must lie inside the frame; out_size % 4 == 0.  Device pointers; asynchronous on
+ * `stream` (indices and weights are computed in the kernel). */
 #define R50_RESIZE_FLOAT 0
 #define R50_RESIZE_FIXED 1
 int r50_op_crop_resize_u8(const void* frames_thwc_u8, int t, int h, int w, int top, int left, int hh, int ww,
