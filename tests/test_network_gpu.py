@@ -230,3 +230,20 @@ def test_uint8_frames_equal_host_normalised_frames(lib_built, precision):
     a = bb.features_u8(u8.to("cuda:0")).cpu()
     b = bb.features(x.to("cuda:0")).cpu()
     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_features_do_not_depend_on_batch_composition(lib_built):
+    """A frame's features are a function of that frame alone: the same bits whether it is run alone, in a batch of 7, or
+    in a batch of 49 (where the tuned large-batch tile table, the persistent kernels and ragged last tiles are in play).
+    This is what lets the CLI take the temporal-reverse variant's features from variant 0 (extract_features)."""
+    from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
+    from implementation_phd_lab_vision_amd.weights import synthetic_frames
+    bb = ResNet50Backbone(seed=0, max_batch=64).to("cuda:0").eval()
+    x = synthetic_frames(49, seed=77).to("cuda:0")
+    big = bb.features(x).clone()
+    assert torch.isfinite(big).all()
+    mid = bb.features(x[3:10]).clone()
+    assert torch.equal(mid, big[3:10])
+    for i in (0, 17, 48):
+        assert torch.equal(bb.features(x[i:i + 1]), big[i:i + 1]), f"frame {i}"
+    assert torch.equal(bb.features(x.flip(0)), big.flip(0))
