@@ -276,7 +276,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
     };
     auto compute = [&]() {
         const char* sbase = smem + c_buf * STAGE_BYTES;
-        if constexpr (BIG) {
+        if constexpr (BIG && (MR * NR + 2 * (MR + NR)) * 4 > 208) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int ph = fphys0 ^ (kk << 6);
@@ -310,6 +310,10 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
 #pragma unroll
                 for (int j = 0; j < NR; ++j)
                     acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][m], xf[kk][j], acc[m][j], 0, 0, 0);
+        if constexpr (BIG) {     // 8-wave tile with room for both halves' fragments: every read of the step first
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MR + NR), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MR * NR, 0);
+        }
         }
     };
     auto epilogue = [&]() {                        // (+ residual) -> bf16 -> ReLU on the packed pair -> 16-B store
