@@ -497,7 +497,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
             const int tap = __builtin_amdgcn_readfirstlane(i_tap);
 #pragma unroll
             for (int i = 0; i < WROWS; ++i)
-#if defined(R50_ABLATE_OOB)
+#if defined(R50_ABLATE_OOB) && (R50_ABLATE_OOB & 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (LDS_AS void*)(sbase + i * PASS_BYTES + lw * 1024), 16,
                                                          kOobOffset | (w_voff[i] & 0u), wofs, 0, 0);
 #else
@@ -506,7 +506,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
 #endif
 #pragma unroll
             for (int i = 0; i < XROWS; ++i) {
-#if defined(R50_ABLATE_OOB)      // diagnostic: every X DMA zero-fills (no L2 traffic for X)
+#if defined(R50_ABLATE_OOB) && (R50_ABLATE_OOB & 1)     // diagnostic: every X DMA zero-fills (no L2 traffic for X)
                 const unsigned voff = kOobOffset | (x_mask[i] & 0u);
 #else
                 const unsigned voff = ((x_mask[i] >> tap) & 1u) ? x_voff[i] : kOobOffset;
