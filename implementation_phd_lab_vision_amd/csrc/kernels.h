@@ -1225,6 +1225,7 @@ struct ResizeArgs {
     int T, H, W, top, left, hh, ww, out;
     int px, py;                 // weight precisions (bits) of the horizontal / vertical pass (fixed-point mode; host-computed)
     int float_mode;             // 1: fp32 arithmetic + round-half-even (torchvision v1 `functional.resize` on uint8)
+    int hflip, trev;            // augmentation variants as index permutations of the OUTPUT: mirror columns / reverse frames
 };
 
 // Source index and the two tap weights of output index i along one axis, computed per thread with the very
@@ -1284,7 +1285,9 @@ __global__ __launch_bounds__(256) void crop_resize_u8_kernel(const ResizeArgs a)
     int y0, wy0, wy1;
     resize_taps(yo, a.hh, a.out, a.py, a.float_mode != 0, y0, wy0, wy1);
     const int y1 = min(y0 + 1, a.hh - 1);
-    const unsigned char* f = a.src + (size_t)t * a.H * a.W * 3;
+    // _aug_temporal_reverse = torch.flip(video, dims=[0]), _aug_hflip = torch.flip(video, dims=[-1]) of the resized clip
+    // (src/dataset.py:158-166,199-207): output frame t / column x takes what the plain resize puts at T-1-t / out-1-x
+    const unsigned char* f = a.src + (size_t)(a.trev ? a.T - 1 - t : t) * a.H * a.W * 3;
     const unsigned char* row0 = f + ((size_t)(a.top + y0) * a.W + a.left) * 3;
     const unsigned char* row1 = f + ((size_t)(a.top + y1) * a.W + a.left) * 3;
     const int rx = 1 << (a.px - 1), ry = 1 << (a.py - 1);
@@ -1293,7 +1296,7 @@ __global__ __launch_bounds__(256) void crop_resize_u8_kernel(const ResizeArgs a)
     for (int q = 0; q < 4; ++q) {
         const int xo = xq * 4 + q;
         int x0, wx0, wx1;
-        resize_taps(xo, a.ww, a.out, a.px, a.float_mode != 0, x0, wx0, wx1);
+        resize_taps(a.hflip ? a.out - 1 - xo : xo, a.ww, a.out, a.px, a.float_mode != 0, x0, wx0, wx1);
         const int x1 = min(x0 + 1, a.ww - 1);                       // float mode: same second index (index0 + (index0 < size-1))
 #pragma unroll
         for (int c = 0; c < 3; ++c) {

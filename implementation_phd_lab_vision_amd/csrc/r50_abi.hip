@@ -1094,12 +1094,15 @@ static int resize_weight_precision(int in_size, int out_size) {
 }
 
 int r50_op_crop_resize_u8(const void* frames, int t, int h, int w, int top, int left, int hh, int ww, void* out, int out_size,
-                          int mode, void* stream) {
+                          int mode, int flags, void* stream) {
     if (!frames || !out || t < 1 || h < 1 || w < 1 || hh < 1 || ww < 1 || top < 0 || left < 0 || top + hh > h || left + ww > w ||
         out_size < 4 || (out_size & 3) || out_size > 4096 || (long long)t * h * w * 3 >= (1ll << 40))
         return fail(nullptr, R50_ERR_INVALID, "r50_op_crop_resize_u8: invalid arguments (the box must lie inside the frame; out_size % 4 == 0)");
     if (mode != R50_RESIZE_FLOAT && mode != R50_RESIZE_FIXED) return fail(nullptr, R50_ERR_INVALID, "r50_op_crop_resize_u8: unknown mode");
+    if (flags & ~(R50_AUG_HFLIP | R50_AUG_TREV)) return fail(nullptr, R50_ERR_INVALID, "r50_op_crop_resize_u8: unknown flags");
     ResizeArgs a;
+    a.hflip = (flags & R50_AUG_HFLIP) ? 1 : 0;
+    a.trev = (flags & R50_AUG_TREV) ? 1 : 0;
     a.float_mode = (mode == R50_RESIZE_FLOAT);
     a.px = a.py = 1;
     if (!a.float_mode) {

@@ -157,11 +157,16 @@ int r50_op_bneck_tail(const void* y2_bf16, int64_t m, int cmid, const void* w3_b
  * mode R50_RESIZE_FIXED: ATen's native uint8 kernel (what the v2 API runs on an AVX2 CPU): two-pass int16 fixed
  * point with a uint8 intermediate, bit-exact.  The box comes from `_compute_square_crop_from_2d` (:75-104; host
  * code, mirrored in frames.py) and must lie inside the frame; out_size % 4 == 0.  Device pointers; asynchronous on
- * `stream` (indices and weights are computed in the kernel). */
+ * `stream` (indices and weights are computed in the kernel).
+ * flags: the two augmentation variants that are index permutations, applied to the output exactly as
+ * the reference applies them to the resized clip: R50_AUG_HFLIP = `torch.flip(video, dims=[-1])` (`_aug_hflip`, :158-166),
+ * R50_AUG_TREV = `torch.flip(video, dims=[0])` (`_aug_temporal_reverse`, :199-207); joints / intrinsics are host code. */
 #define R50_RESIZE_FLOAT 0
 #define R50_RESIZE_FIXED 1
+#define R50_AUG_HFLIP 1
+#define R50_AUG_TREV 2
 int r50_op_crop_resize_u8(const void* frames_thwc_u8, int t, int h, int w, int top, int left, int hh, int ww,
-                          void* out_tchw_u8, int out_size, int mode, void* stream);
+                          void* out_tchw_u8, int out_size, int mode, int flags, void* stream);
 
 /* AdaptiveAvgPool2d((1,1)) + flatten(1): (n,hw,c) bf16 -> (n,c) fp32; c % 8 == 0. */
 int r50_op_avgpool(const void* x_nhwc_bf16, int n, int hw, int c, float* y_f32, void* stream);

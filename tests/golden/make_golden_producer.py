@@ -1,6 +1,6 @@
 """Golden vectors for the frame producer's host functions (implementation_phd_lab_vision_amd/frames.py), produced by
 the REFERENCE's own functions: ``_compute_square_crop_from_2d``, ``_adjust_joints2d_after_crop_and_resize``,
-``_adjust_camera_after_crop_and_resize`` of src/dataset.py, imported from /root/reference with ``torchvision`` (absent
+``_adjust_camera_after_crop_and_resize``, ``_aug_hflip``, ``_aug_temporal_reverse`` of src/dataset.py, imported from /root/reference with ``torchvision`` (absent
 from this image, unused by these three functions) replaced by empty stub modules.  Inputs are seeded; the file holds
 inputs and expected outputs only.
 
@@ -50,8 +50,14 @@ def main():
         cam = {"f": (torch.rand(2, generator=g) * 500 + 900).numpy().astype(np.float64),
                "c": (torch.rand(2, generator=g) * 100 + 450).numpy().astype(np.float64)}
         k = ref._adjust_camera_after_crop_and_resize(cam, box, out_size=224)
+        joints3d = torch.randn(t, 17, 3, generator=g) * 500.0
+        dummy_video = torch.zeros(t, 3, 2, 224)
+        _v, j3_f, j2_f, k_f = ref._aug_hflip(dummy_video, joints3d, j2, k)
+        _v, j3_r, j2_r = ref._aug_temporal_reverse(dummy_video, joints3d, j2)
         cases.append({"img_h": img_h, "img_w": img_w, "joints2d": joints2d, "box": box, "joints2d_adjusted": j2,
-                      "cam_f": torch.from_numpy(cam["f"]), "cam_c": torch.from_numpy(cam["c"]), "K": k})
+                      "cam_f": torch.from_numpy(cam["f"]), "cam_c": torch.from_numpy(cam["c"]), "K": k,
+                      "joints3d": joints3d, "hflip_j3d": j3_f, "hflip_j2d": j2_f, "hflip_K": k_f,
+                      "trev_j3d": j3_r, "trev_j2d": j2_r})
     torch.save(cases, os.path.join(HERE, "producer_golden.pt"))
     print("wrote", len(cases), "cases; boxes:", [c["box"].tolist() for c in cases[:6]])
 

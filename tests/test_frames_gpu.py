@@ -60,6 +60,20 @@ def test_float_mode_matches_reference_route(lib_built, case):
     assert d.max() <= 1 and (d > 0).mean() <= 1e-4
 
 
+@pytest.mark.parametrize("mode", [0, 1], ids=["float", "fixed"])
+def test_hflip_and_trev_are_flips_of_the_plain_output(lib_built, mode):
+    """The augmentation variants that are index permutations (src/dataset.py:158-166,199-207): the kernel's flags must
+    give exactly torch.flip of its own plain output along W / T."""
+    from implementation_phd_lab_vision_amd import frames
+    fr = _frames(260, 300, 5, 99).to("cuda:0")
+    box = [13, 40, 211, 211]
+    plain = frames.crop_and_resize_video_uint8(fr, box, mode=mode)
+    assert torch.equal(frames.crop_and_resize_video_uint8(fr, box, mode=mode, hflip=True), torch.flip(plain, dims=[-1]))
+    assert torch.equal(frames.crop_and_resize_video_uint8(fr, box, mode=mode, trev=True), torch.flip(plain, dims=[0]))
+    assert torch.equal(frames.crop_and_resize_video_uint8(fr, box, mode=mode, hflip=True, trev=True),
+                       torch.flip(plain, dims=[0, -1]))
+
+
 def test_box_outside_frame_is_refused(lib_built):
     from implementation_phd_lab_vision_amd import frames, _lib
     fr = torch.zeros((1, 32, 32, 3), dtype=torch.uint8, device="cuda:0")

@@ -64,6 +64,10 @@ def test_host_functions_match_reference_goldens():
         assert torch.equal(frames.adjust_joints2d_after_crop_and_resize(c["joints2d"], box), c["joints2d_adjusted"])
         k = frames.adjust_camera_after_crop_and_resize({"f": c["cam_f"].numpy(), "c": c["cam_c"].numpy()}, box)
         assert k.dtype == torch.float32 and torch.equal(k, c["K"])
+        j3f, j2f, kf = frames.aug_hflip_annotations(c["joints3d"], c["joints2d_adjusted"], k)
+        assert torch.equal(j3f, c["hflip_j3d"]) and torch.equal(j2f, c["hflip_j2d"]) and torch.equal(kf, c["hflip_K"])
+        j3r, j2r = frames.aug_temporal_reverse_annotations(c["joints3d"], c["joints2d_adjusted"])
+        assert torch.equal(j3r, c["trev_j3d"]) and torch.equal(j2r, c["trev_j2d"])
 
 
 def test_device_op_refuses_cpu_tensors():
