@@ -543,7 +543,11 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
             if (g + D < total) stage_issue();
             R50_MARK(0)                                  // DMA issue
             // stages issued so far: 0 .. min(g+D, total-1); stage g+1 must be complete
+#if defined(R50_ABLATE_WS) && (R50_ABLATE_WS & 8)
+            if (false) {
+#else
             if (g + D < total) {
+#endif
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LOADS_PER_STAGE) : "memory");
             } else if (D >= 3 && g + D - 1 < total) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D >= 3 ? D - 2 : 0) * LOADS_PER_STAGE) : "memory");
@@ -657,7 +661,11 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
 #pragma unroll
                         for (int e = 0; e < 4; ++e) out[e] = relu_bf16x2(out[e]);
                     }
+#if defined(R50_ABLATE_WS) && (R50_ABLATE_WS & 4)
+                    if (out[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, 0);
+#else
                     __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, 0);
+#endif
                 }
             }
         };
