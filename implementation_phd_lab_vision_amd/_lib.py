@@ -85,6 +85,10 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own copy of the HIP runtime.  Import it first so that libr50hip.so binds to the runtime that is
+    # already in the process: loaded the other way round (library, then torch) the process ends up with two runtimes and
+    # this library's one sees no device.
+    import torch  # noqa: F401
     if not LIB_PATH.exists():
         raise R50Error(f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
                        "There is no CPU/PyTorch fallback for this path.")
