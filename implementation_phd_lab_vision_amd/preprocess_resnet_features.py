@@ -58,6 +58,8 @@ def build_parser() -> argparse.ArgumentParser:
                    help="bf16 = the reference's CUDA autocast dtype (fast); fp32x = fp32-class accuracy (its CPU numerics), ~2.7x slower")
     p.add_argument("--micro-batch", type=int, default=0, help="Frames per pass through the layer stack (0 = auto)")
     p.add_argument("--max-batch", type=int, default=256, help="Frames per backbone call chunk (workspace size)")
+    p.add_argument("--no-trev-reuse", action="store_true",
+                   help="--augment: run the backbone on the temporal-reverse variant too instead of flipping variant 0's features")
     return p
 
 
@@ -180,7 +182,7 @@ def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.Ran
             else:
                 video, j3d, j2d, k, box = batch
                 variants_batch, box_batch = [(video, j3d, j2d, k)], box
-            feats = extract_features(backbone, variants_batch, device)
+            feats = extract_features(backbone, variants_batch, device, reuse_trev=not getattr(args, "no_trev_reuse", False))
             payload = _host_payload(variants_batch, box_batch)
             t = variants_batch[0][0].shape[1]
         else:

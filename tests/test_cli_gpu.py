@@ -32,3 +32,22 @@ def test_cli_end_to_end(tmp_path, lib_built):
         assert torch.equal(shard["joints3d"][rec["row"]], j3d) and torch.equal(shard["K"][rec["row"]], k)
         assert torch.equal(shard["meta"][rec["row"]]["box"], box)
     assert len(seen) == 7
+
+
+def test_cli_augment_trev_reuse_gives_identical_files(tmp_path, lib_built):
+    """--augment on the MI355X: the shards written with the temporal-reverse shortcut (variant 3 = variant 0's features in
+    reverse frame order, 3 forward passes) equal, tensor for tensor, the shards written with all 4 forward passes."""
+    from implementation_phd_lab_vision_amd.preprocess_resnet_features import main
+    common = ["--root", "unused", "--synthetic-clips", "5", "--seq-len", "3", "--batch-size", "2", "--num-workers", "0",
+              "--shard-size", "3", "--shuffle-pool", "4", "--shuffle-seed", "3", "--device", "cuda", "--max-batch", "16", "--augment"]
+    a, b = tmp_path / "reuse", tmp_path / "full"
+    main(common + ["--out", str(a)])
+    main(common + ["--out", str(b), "--no-trev-reuse"])
+    ia, ib = torch.load(a / "index.pt", weights_only=True), torch.load(b / "index.pt", weights_only=True)
+    assert ia["n_variants"] == 4 and ia["clips"] == ib["clips"] and ia["n_shards"] == ib["n_shards"]
+    for sid in range(ia["n_shards"]):
+        sa = torch.load(a / f"shard_{sid:05d}.pt", weights_only=True)
+        sb = torch.load(b / f"shard_{sid:05d}.pt", weights_only=True)
+        for key in ("feats", "joints3d", "joints2d", "K"):
+            assert torch.equal(sa[key], sb[key]), (sid, key)
+        assert [m["aug"] for m in sa["meta"]] == [m["aug"] for m in sb["meta"]]
