@@ -85,7 +85,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=BATCH, help="frames per GPU per step (headline config: 256)")
     ap.add_argument("--micro-batch", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="internal streams the batch is split over (0 = library default)")
-    ap.add_argument("--precision", choices=["bf16", "fp32x"], default="bf16",
+    ap.add_argument("--precision", choices=["bf16", "bf16w2", "fp32x"], default="bf16",
                     help="bf16 = headline path; fp32x = fp32-class accuracy mode (bf16 head/tail pairs, 3 products per conv)")
     ap.add_argument("--input", choices=["f32", "u8", "video"], default="f32",
                     help="f32 = the reference boundary (normalised fp32 NCHW frames); u8 = resized uint8 crops, normalised in the stem "

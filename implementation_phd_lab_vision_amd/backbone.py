@@ -24,7 +24,9 @@ from .weights import FEATURE_DIM, iter_named_tensors, load_state_dict_from_path,
 
 PREC_BF16 = 1     # bf16 operands, fp32 accumulation: the fast path (the reference's CUDA autocast dtype)
 PREC_FP32X = 2    # fp32-class accuracy on the bf16 matrix cores (bf16 head/tail pairs, 3 products per conv)
-_PRECISIONS = {"bf16": PREC_BF16, "fp32x": PREC_FP32X, PREC_BF16: PREC_BF16, PREC_FP32X: PREC_FP32X}
+PREC_BF16W2 = 3   # bf16 activations, weights as bf16 head/tail pairs (2 products per conv): within 1e-3 of the fp32 reference
+_PRECISIONS = {"bf16": PREC_BF16, "fp32x": PREC_FP32X, "bf16w2": PREC_BF16W2, PREC_BF16: PREC_BF16, PREC_FP32X: PREC_FP32X,
+               PREC_BF16W2: PREC_BF16W2}
 
 
 class ResNet50Backbone:
@@ -43,7 +45,7 @@ class ResNet50Backbone:
         self._max_batch = int(max_batch)
         self._micro_batch = int(micro_batch)
         if precision not in _PRECISIONS:
-            raise ValueError(f"precision must be 'bf16' or 'fp32x', got {precision!r}")
+            raise ValueError(f"precision must be 'bf16', 'bf16w2' or 'fp32x', got {precision!r}")
         self._precision = _PRECISIONS[precision]
         self._handle: Optional[int] = None
         self._device: Optional[torch.device] = None

@@ -492,7 +492,8 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
         auto stage_issue = [&]() {
             char* sbase = smem + i_buf * STAGE_BYTES;
             // soffset has to be an SGPR: without the readfirstlane the compiler wraps every DMA in a waterfall loop
-            const int xofs = __builtin_amdgcn_readfirstlane(i_tapofs + i_cc * 128);
+            const int xcc = (i_cc >= a.x_wrap) ? i_cc - a.x_wrap : i_cc;     // bf16w2 mode: K per tap is [x | x] against [w_head | w_tail]
+            const int xofs = __builtin_amdgcn_readfirstlane(i_tapofs + xcc * 128);
             const int wofs = __builtin_amdgcn_readfirstlane(i_wofs);
             const int tap = __builtin_amdgcn_readfirstlane(i_tap);
 #pragma unroll

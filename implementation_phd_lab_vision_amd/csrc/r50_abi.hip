@@ -166,6 +166,21 @@ void pack_ohwi_split(const float* wf, int cout, int cin, int ks, std::vector<uin
             }
 }
 
+// bf16w2 mode: (cout, cin, k, k) fp32 -> (cout, k, k, [w_head(cin) | w_tail(cin)]) bf16; pairs with X = [x | x]
+// (the X chunk index wraps after cin/64, ConvArgs::x_wrap), i.e. x*w_head + x*w_tail with ONE fp32 accumulator.
+void pack_ohwi_w2(const float* wf, int cout, int cin, int ks, std::vector<uint16_t>& out) {
+    out.resize((size_t)cout * ks * ks * 2 * cin);
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < ks * ks; ++t) {
+                const float w = wf[((size_t)o * cin + c) * ks * ks + t];
+                const uint16_t hd = f32_to_bf16_rne(w);
+                const uint16_t tl = f32_to_bf16_rne(w - bf16_to_f32(hd));
+                uint16_t* row = &out[((size_t)o * ks * ks + t) * 2 * cin];
+                row[c] = hd; row[cin + c] = tl;
+            }
+}
+
 inline int perm_row_to_cout(int rho) {   // LDS/MFMA row -> channel inside a 32-row group (kernels.h)
     return (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
 }
@@ -287,7 +302,7 @@ hipError_t launch_igemm_ws_t(ConvArgs a, hipStream_t s) {
 constexpr int kTileC64 = kWsBit | 16;
 bool is_c64_shape(const ConvArgs& a) {
     return a.ks == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 64 && a.Cout == 64 && a.H == 56 && a.W == 56 && a.res == nullptr &&
-           a.x_cstride == 64 && a.y_cstride == 64;
+           a.x_cstride == 64 && a.y_cstride == 64 && a.Ktot == 576;
 }
 hipError_t launch_conv3x3_c64(const ConvArgs& a, hipStream_t s) {
     if (!is_c64_shape(a)) return hipErrorInvalidValue;
@@ -353,7 +368,7 @@ hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s, bool split =
 }
 
 int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, const void* wt, const float* bias,
-                   const void* res, void* y, int cout, int ks, int stride, int pad, int relu, bool split = false) {
+                   const void* res, void* y, int cout, int ks, int stride, int pad, int relu, bool split = false, bool w2 = false) {
     if (!x || !wt || !bias || !y) return R50_ERR_INVALID;
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cin % 64 || cout <= 0 || cout % 64) return R50_ERR_INVALID;
     if (!(ks == 1 || ks == 3) || stride < 1 || pad < 0 || 2 * pad > ks - 1) return R50_ERR_INVALID;
@@ -371,8 +386,10 @@ int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, con
     // split mode: X is [head(cin) | tail(cin)] per pixel, K per tap is 3*cin, Y is [head(cout) | tail(cout)]
     a.x_cstride = split ? 2 * cin : cin;
     a.y_cstride = split ? 2 * cout : cout;
-    a.x_wrap = split ? 2 * (cin / 64) : (1 << 30);
-    a.cin_chunks = (split ? 3 : 1) * (cin / 64); a.nk = ks * ks * a.cin_chunks; a.Ktot = ks * ks * (split ? 3 : 1) * cin;
+    // bf16w2 mode: X plain, K per tap is 2*cin = [x | x] against [w_head | w_tail]
+    const int kmul = split ? 3 : (w2 ? 2 : 1);
+    a.x_wrap = split ? 2 * (cin / 64) : (w2 ? cin / 64 : (1 << 30));
+    a.cin_chunks = kmul * (cin / 64); a.nk = ks * ks * a.cin_chunks; a.Ktot = ks * ks * kmul * cin;
     a.n_ctiles = 0; a.n_blocks = 0;
     // buffer descriptors of the kernel (kernels.h): every offset must stay below 2^31
     const long long x_bytes = (long long)n * h * w * a.x_cstride * 2;
@@ -475,7 +492,8 @@ int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, 
              __bf16* y, int relu, hipStream_t s, int* ho, int* wo) {
     ConvArgs a;
     const bool split = (h->precision == R50_PREC_FP32X);
-    int rc = fill_conv_args(a, x, n, hh, ww, L.cin, L.w, L.bias, res, y, L.cout, L.ks, L.stride, L.pad, relu, split);
+    const bool w2 = (h->precision == R50_PREC_BF16W2);
+    int rc = fill_conv_args(a, x, n, hh, ww, L.cin, L.w, L.bias, res, y, L.cout, L.ks, L.stride, L.pad, relu, split, w2);
     if (rc) return fail(h, rc, "conv args invalid for " + L.conv_key);
     EvRec r{};
     const double flops = 2.0 * a.M * (double)a.Cout * L.ks * L.ks * L.cin;       // algorithmic (not the 3x of split mode)
@@ -648,7 +666,7 @@ after_pool:
             // block the identity (downsample conv of the block input) is computed inside that kernel as well
             const size_t li_next = li + ((b == 0) ? 4 : 3);
             const ConvLayer* nx = (li_next < h->convs.size()) ? &h->convs[li_next] : nullptr;
-            const bool fuse_ok = !split && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
+            const bool fuse_ok = !split && h->precision == R50_PREC_BF16 && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
                                  nx->ks == 1 && nx->stride == 1;
             const bool fuse2 = fuse_ok && c3.cin == 128 && c3.cout == 512 && nx->cin == 512 && nx->cout == 128;   // layer2 shapes
             const bool fuse = (fuse_ok && c3.cin == 64 && c3.cout == 256 && nx->cin == 256 && (nx->cout == 64 || nx->cout == 128)) ||
@@ -805,7 +823,7 @@ const char* r50_last_error(r50_handle* h) { return h ? h->err.c_str() : g_err.c_
 int r50_create(r50_handle** out, int device_id, int precision, int max_batch) {
     if (!out) return fail(nullptr, R50_ERR_INVALID, "r50_create: out is null");
     *out = nullptr;
-    if (precision != R50_PREC_BF16 && precision != R50_PREC_FP32X)
+    if (precision != R50_PREC_BF16 && precision != R50_PREC_FP32X && precision != R50_PREC_BF16W2)
         return fail(nullptr, R50_ERR_INVALID, "r50_create: unsupported precision");
     const int cmul = (precision == R50_PREC_FP32X) ? 2 : 1;
     if (max_batch < 1 || max_batch > 1024) return fail(nullptr, R50_ERR_INVALID, "r50_create: max_batch must be in [1,1024]");
@@ -901,6 +919,7 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
             }
         } else {
             if (split) pack_ohwi_split(wf.data(), L.cout, L.cin, L.ks, pk);
+            else if (h->precision == R50_PREC_BF16W2) pack_ohwi_w2(wf.data(), L.cout, L.cin, L.ks, pk);
             else pack_ohwi_bf16(wf.data(), L.cout, L.cin, L.ks, pk);
             if (!L.w) HIP_TRY(h, hipMalloc((void**)&L.w, pk.size() * 2));
             HIP_TRY(h, hipMemcpy(L.w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
@@ -1017,7 +1036,7 @@ int r50_get_packed(r50_handle* h, const char* conv_key, int what, void* dst_host
         int64_t bytes;
         if (what == 1) { src = L.bias; bytes = (int64_t)L.cout * 4; }
         else if (i == 0) { src = h->stem_w; bytes = STEM_W_BYTES; }
-        else { src = L.w; bytes = (int64_t)L.cout * L.ks * L.ks * L.cin * 2; }
+        else { src = L.w; bytes = (int64_t)L.cout * L.ks * L.ks * L.cin * 2 * (h->precision == R50_PREC_FP32X ? 3 : h->precision == R50_PREC_BF16W2 ? 2 : 1); }
         *bytes_out = bytes;
         if (bytes > capacity_bytes) return fail(h, R50_ERR_INVALID, "r50_get_packed: buffer too small");
         HIP_TRY(h, hipMemcpy(dst_host, src, bytes, hipMemcpyDeviceToHost));

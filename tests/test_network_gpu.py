@@ -247,3 +247,29 @@ def test_features_do_not_depend_on_batch_composition(lib_built):
     for i in (0, 17, 48):
         assert torch.equal(bb.features(x[i:i + 1]), big[i:i + 1]), f"frame {i}"
     assert torch.equal(bb.features(x.flip(0)), big.flip(0))
+
+
+def test_bf16w2_precision_meets_1e3_of_the_fp32_reference(lib_built):
+    """bf16w2: bf16 activations, every bottleneck conv weight a bf16 (head, tail) pair, two MFMA products per conv.  The
+    bf16 error of this network is weight-rounding dominated (oracle: fp32 weights + bf16 activations 8e-4, bf16 weights +
+    fp32 activations 2.3e-3), so this mode lands within north_star's 1e-3 of the fp32/fp64 reference view, and tracks
+    its own emulation (same rounding points) like the bf16 mode does."""
+    from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
+    from implementation_phd_lab_vision_amd.weights import synthetic_frames, synthetic_state_dict
+    from oracle import resnet50_oracle as O
+    sd = synthetic_state_dict(0)
+    x = synthetic_frames(3, seed=11)
+    bb = ResNet50Backbone(state_dict=sd, max_batch=4, precision="bf16w2").to("cuda:0").eval()
+    got = bb.features(x.to("cuda:0")).cpu()
+    assert torch.isfinite(got).all()
+    ref = O.forward_reference(sd, x, dtype=torch.float64).float()
+    emu = O.forward_bf16_emulated(sd, x, weight_terms=2)
+    r_ref = O.per_row_rel_l2(got, ref)
+    r_emu = O.per_row_rel_l2(got, emu)
+    assert float(r_ref.max()) < 1e-3, f"bf16w2 vs fp64 reference: {r_ref.tolist()}"
+    assert float(r_emu.max()) < 1e-3, f"bf16w2 vs its emulation: {r_emu.tolist()}"
+    # and a mid-network tap against the emulation's tap
+    taps = {}
+    O.forward_bf16_emulated(sd, x, taps=taps, weight_terms=2)
+    t = bb.layer(x.to("cuda:0"), "layer2.1").float().cpu().permute(0, 3, 1, 2)
+    assert O.rel_l2(t, taps["layer2.1"]) < 2e-3
