@@ -85,7 +85,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=BATCH, help="frames per GPU per step (headline config: 256)")
     ap.add_argument("--micro-batch", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="internal streams the batch is split over (0 = library default)")
-    ap.add_argument("--precision", choices=["bf16", "bf16w2", "fp32x"], default="bf16",
+    ap.add_argument("--precision", choices=["bf16", "fp16", "bf16w2", "fp32x"], default="bf16",
                     help="bf16 = headline path; fp32x = fp32-class accuracy mode (bf16 head/tail pairs, 3 products per conv)")
     ap.add_argument("--input", choices=["f32", "u8", "video"], default="f32",
                     help="f32 = the reference boundary (normalised fp32 NCHW frames); u8 = resized uint8 crops, normalised in the stem "
@@ -240,7 +240,8 @@ def main() -> None:
             "metric": "H36M frames/sec ResNet-50 feature extraction",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (fp32-class)", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "fp16", "bf16w2": "bf16 (weights as bf16 head+tail pairs)",
+                                            "fp32x": "bf16x3 (fp32-class)"}[args.precision], "data": "synthetic",
             "config": {"workload": f"ResNet-50[:-1] bf16 forward, batch {args.batch} x 224x224x3 fp32 NCHW frames per GPU "
                                    f"(BASELINE configs[1]), seeded synthetic weights, (N,2048) fp32 features"
                                    + (", RCCL gather to rank 0" if world > 1 else ""),

@@ -25,8 +25,9 @@ from .weights import FEATURE_DIM, iter_named_tensors, load_state_dict_from_path,
 PREC_BF16 = 1     # bf16 operands, fp32 accumulation: the fast path (the reference's CUDA autocast dtype)
 PREC_FP32X = 2    # fp32-class accuracy on the bf16 matrix cores (bf16 head/tail pairs, 3 products per conv)
 PREC_BF16W2 = 3   # bf16 activations, weights as bf16 head/tail pairs (2 products per conv): within 1e-3 of the fp32 reference
-_PRECISIONS = {"bf16": PREC_BF16, "fp32x": PREC_FP32X, "bf16w2": PREC_BF16W2, PREC_BF16: PREC_BF16, PREC_FP32X: PREC_FP32X,
-               PREC_BF16W2: PREC_BF16W2}
+PREC_FP16 = 4     # IEEE half operands / activations, same kernels and speed as bf16; 3e-4 from the fp32 reference
+_PRECISIONS = {"bf16": PREC_BF16, "fp32x": PREC_FP32X, "bf16w2": PREC_BF16W2, "fp16": PREC_FP16, PREC_BF16: PREC_BF16,
+               PREC_FP32X: PREC_FP32X, PREC_BF16W2: PREC_BF16W2, PREC_FP16: PREC_FP16}
 
 
 class ResNet50Backbone:
@@ -45,7 +46,7 @@ class ResNet50Backbone:
         self._max_batch = int(max_batch)
         self._micro_batch = int(micro_batch)
         if precision not in _PRECISIONS:
-            raise ValueError(f"precision must be 'bf16', 'bf16w2' or 'fp32x', got {precision!r}")
+            raise ValueError(f"precision must be 'bf16', 'fp16', 'bf16w2' or 'fp32x', got {precision!r}")
         self._precision = _PRECISIONS[precision]
         self._handle: Optional[int] = None
         self._device: Optional[torch.device] = None
@@ -153,8 +154,8 @@ class ResNet50Backbone:
         return self.features_u8(crop_and_resize_video_uint8(frames_thwc_u8, box, 224, mode))
 
     def layer(self, x: torch.Tensor, name: str) -> torch.Tensor:
-        """Debug hook: named intermediate activation, NHWC (per-layer parity tests).  bf16 tensor in bf16
-        mode; in fp32x mode the (head, tail) pair is recombined into an fp32 tensor."""
+        """Debug hook: named intermediate activation, NHWC (per-layer parity tests).  bf16 tensor in the bf16
+        modes, fp16 tensor in fp16 mode; in fp32x mode the (head, tail) pair is recombined into an fp32 tensor."""
         x = self._check_input(x)
         n = x.shape[0]
         lib = _lib.load_library()
@@ -169,6 +170,8 @@ class ResNet50Backbone:
         if self._precision == PREC_FP32X:
             c = d[3] // 2
             return t[..., :c].float() + t[..., c:].float()
+        if self._precision == PREC_FP16:          # same bytes, the other 16-bit format
+            return t.view(torch.float16)
         return t
 
     def packed_params(self, conv_key: str):

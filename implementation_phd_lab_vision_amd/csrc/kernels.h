@@ -28,6 +28,42 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned int, b);
 }
 
+// Element type of operands and activations: ET 0 = bf16, ET 1 = fp16 (IEEE half).  Both are 2 bytes, so every layout,
+// DMA and LDS image is shared; only the MFMA opcode and the fp32 <-> element conversions differ.  (`bf16x8` is used as the
+// name of "a 16-byte MFMA operand register" for both.)  fp16 carries 11 significand bits instead of 8: with fp16 operands
+// the whole network lands 3e-4 from the fp32 reference (bf16: 2.5e-3, almost all of it weight rounding) at the same speed;
+// its range (65504) is far above anything a BN-folded ResNet-50 produces, and the conversion saturates instead of
+// overflowing to infinity.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+template <int ET>
+__device__ __forceinline__ f32x4 mfma_e(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (ET == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <int ET>
+__device__ __forceinline__ unsigned int pack2_e(float lo, float hi) {     // two fp32 -> packed pair, round to nearest even
+    if constexpr (ET == 0) {
+        return pack_bf16x2(lo, hi);
+    } else {
+        lo = __builtin_fminf(__builtin_fmaxf(lo, -65504.0f), 65504.0f);
+        hi = __builtin_fminf(__builtin_fmaxf(hi, -65504.0f), 65504.0f);
+        const f16x2 b = {(_Float16)lo, (_Float16)hi};                   // v_cvt_pk_f16_f32
+        return __builtin_bit_cast(unsigned int, b);
+    }
+}
+template <int ET>
+__device__ __forceinline__ float unpack_lo_e(unsigned int u) {
+    if constexpr (ET == 0) return bf16_bits_to_f32(u & 0xffffu);
+    else return (float)__builtin_bit_cast(f16x2, u)[0];
+}
+template <int ET>
+__device__ __forceinline__ float unpack_hi_e(unsigned int u) {
+    if constexpr (ET == 0) return __uint_as_float(u & 0xffff0000u);
+    else return (float)__builtin_bit_cast(f16x2, u)[1];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution (k = 1 or 3, stride 1 or 2), fused folded-BN bias + residual + ReLU.
 //
@@ -90,6 +126,7 @@ struct ConvArgs {
     int x_cstride;        // channels per pixel of the X tensor (Cin; 2*Cin in split mode: [hi | lo])
     int x_wrap;           // K chunk index at which the X chunk index wraps to 0 again (split: 2*Cin/64; else huge)
     int y_cstride;        // channels per pixel of Y / residual (Cout; 2*Cout in split mode)
+    int et;               // element type of operands / activations: 0 = bf16, 1 = fp16 (host-side dispatch only)
 #if defined(R50_STAMP)    // diagnostic build (scripts/stamp_conv.py): per-wave cycle sums, 8 slots per wave
     unsigned long long* dbg;
 #endif
@@ -127,7 +164,7 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned v) {   // max(x, 0) on 
 
 constexpr unsigned kOobOffset = 0x80000000u;
 
-template <int BC, int BP, int WC, int WP, int NSTAGE, bool SPLIT = false>
+template <int ET, int BC, int BP, int WC, int WP, int NSTAGE, bool SPLIT = false>
 __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body only in the device pass: the host pass needs just the launch stub
                                       // (the LDS-DMA buffer builtin has no host-side lowering)
@@ -289,7 +326,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
                     for (int j = 0; j < NR; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[j], acc[m][j], 0, 0, 0);
+                        acc[m][j] = mfma_e<ET>(wf[m], xf[j], acc[m][j]);
             }
         } else {
         bf16x8 wf[2][MR], xf[2][NR];
@@ -309,7 +346,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
             for (int m = 0; m < MR; ++m)
 #pragma unroll
                 for (int j = 0; j < NR; ++j)
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][m], xf[kk][j], acc[m][j], 0, 0, 0);
+                    acc[m][j] = mfma_e<ET>(wf[kk][m], xf[kk][j], acc[m][j]);
         if constexpr (BIG) {     // 8-wave tile with room for both halves' fragments: every read of the step first
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MR + NR), 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * MR * NR, 0);
@@ -328,13 +365,13 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
                         u32x4 r;
                         if constexpr (PREFETCH_RES) r = res_reg[t][j];
                         else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, 0, 0);
-                        lo[0] += bf16_bits_to_f32(r[0] & 0xffffu); lo[1] += __uint_as_float(r[0] & 0xffff0000u);
-                        lo[2] += bf16_bits_to_f32(r[1] & 0xffffu); lo[3] += __uint_as_float(r[1] & 0xffff0000u);
-                        hi[0] += bf16_bits_to_f32(r[2] & 0xffffu); hi[1] += __uint_as_float(r[2] & 0xffff0000u);
-                        hi[2] += bf16_bits_to_f32(r[3] & 0xffffu); hi[3] += __uint_as_float(r[3] & 0xffff0000u);
+                        lo[0] += unpack_lo_e<ET>(r[0]); lo[1] += unpack_hi_e<ET>(r[0]);
+                        lo[2] += unpack_lo_e<ET>(r[1]); lo[3] += unpack_hi_e<ET>(r[1]);
+                        hi[0] += unpack_lo_e<ET>(r[2]); hi[1] += unpack_hi_e<ET>(r[2]);
+                        hi[2] += unpack_lo_e<ET>(r[3]); hi[3] += unpack_hi_e<ET>(r[3]);
                     }
-                    u32x4 out = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                                        pack_bf16x2(hi[2], hi[3])};
+                    u32x4 out = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]),
+                                        pack2_e<ET>(hi[2], hi[3])};
                     if (a.relu) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) out[e] = relu_bf16x2(out[e]);
@@ -348,8 +385,8 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
                         const u32x4 rl = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, a.Cout * 2, 0);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[2 * e] += bf16_bits_to_f32(rh[e] & 0xffffu) + bf16_bits_to_f32(rl[e] & 0xffffu);
-                            v[2 * e + 1] += __uint_as_float(rh[e] & 0xffff0000u) + __uint_as_float(rl[e] & 0xffff0000u);
+                            v[2 * e] += unpack_lo_e<ET>(rh[e]) + unpack_lo_e<ET>(rl[e]);
+                            v[2 * e + 1] += unpack_hi_e<ET>(rh[e]) + unpack_hi_e<ET>(rl[e]);
                         }
                     }
                     if (a.relu) {
@@ -359,9 +396,9 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
                     u32x4 head, tail;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        head[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                        tail[e] = pack_bf16x2(v[2 * e] - bf16_bits_to_f32(head[e] & 0xffffu),
-                                              v[2 * e + 1] - __uint_as_float(head[e] & 0xffff0000u));
+                        head[e] = pack2_e<ET>(v[2 * e], v[2 * e + 1]);
+                        tail[e] = pack2_e<ET>(v[2 * e] - unpack_lo_e<ET>(head[e]),
+                                              v[2 * e + 1] - unpack_hi_e<ET>(head[e]));
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(head, rsrc_y, voff, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(tail, rsrc_y, voff, a.Cout * 2, 0);
@@ -410,7 +447,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
 // WAR: stage g+D goes into the buffer of stage g-1, which the consumers finished before the barrier ending
 //      step g-1.
 // ------------------------------------------------------------------------------------------------
-template <int BC, int BP, int CWC, int CWP, int NLOAD, int NSTAGE>
+template <int ET, int BC, int BP, int CWC, int CWP, int NLOAD, int NSTAGE>
 __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NCONS = CWC * CWP;
@@ -629,9 +666,9 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
 #pragma unroll
                     for (int j = 0; j < NR; ++j)
 #if defined(R50_ABLATE_MFMA)    // diagnostic: one MFMA per fragment pair column instead of MR*NR (keeps every LDS read live)
-                        { if (m == 0 || j == 0) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][m], xf[kk][j], acc[m][j], 0, 0, 0); }
+                        { if (m == 0 || j == 0) acc[m][j] = mfma_e<ET>(wf[kk][m], xf[kk][j], acc[m][j]); }
 #else
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][m], xf[kk][j], acc[m][j], 0, 0, 0);
+                        acc[m][j] = mfma_e<ET>(wf[kk][m], xf[kk][j], acc[m][j]);
 #endif
 #if !defined(R50_ABLATE_MFMA)
             if constexpr (NCONS + NLOAD <= 8) {     // 2 waves per SIMD: 256 registers, room for both halves' fragments
@@ -651,13 +688,13 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
                         u32x4 r;
                         if constexpr (PREFETCH_RES) r = res_reg[t][j];
                         else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, 0, 0);
-                        lo[0] += bf16_bits_to_f32(r[0] & 0xffffu); lo[1] += __uint_as_float(r[0] & 0xffff0000u);
-                        lo[2] += bf16_bits_to_f32(r[1] & 0xffffu); lo[3] += __uint_as_float(r[1] & 0xffff0000u);
-                        hi[0] += bf16_bits_to_f32(r[2] & 0xffffu); hi[1] += __uint_as_float(r[2] & 0xffff0000u);
-                        hi[2] += bf16_bits_to_f32(r[3] & 0xffffu); hi[3] += __uint_as_float(r[3] & 0xffff0000u);
+                        lo[0] += unpack_lo_e<ET>(r[0]); lo[1] += unpack_hi_e<ET>(r[0]);
+                        lo[2] += unpack_lo_e<ET>(r[1]); lo[3] += unpack_hi_e<ET>(r[1]);
+                        hi[0] += unpack_lo_e<ET>(r[2]); hi[1] += unpack_hi_e<ET>(r[2]);
+                        hi[2] += unpack_lo_e<ET>(r[3]); hi[3] += unpack_hi_e<ET>(r[3]);
                     }
-                    u32x4 out = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                                        pack_bf16x2(hi[2], hi[3])};
+                    u32x4 out = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]),
+                                        pack2_e<ET>(hi[2], hi[3])};
                     if (a.relu) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) out[e] = relu_bf16x2(out[e]);
@@ -715,6 +752,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
 // COLUMN so that a tap's row shift (kh*58 rows) is an immediate offset and only the 3 column shifts need their
 // own address registers.
 // ------------------------------------------------------------------------------------------------
+template <int ET>
 __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int W_BYTES = 9 * 64 * 128;             // 73,728
@@ -825,8 +863,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
                 if (it + 1 < 18) read_block(it + 1, wf[(it + 1) & 1], xf[(it + 1) & 1]);
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[it & 1][0], xf[it & 1][j], acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[it & 1][1], xf[it & 1][j], acc[1][j], 0, 0, 0);
+                    acc[0][j] = mfma_e<ET>(wf[it & 1][0], xf[it & 1][j], acc[0][j]);
+                    acc[1][j] = mfma_e<ET>(wf[it & 1][1], xf[it & 1][j], acc[1][j]);
                 }
                 if (it + 1 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
@@ -837,8 +875,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 const f32x4 lo = acc[0][j], hi = acc[1][j];
-                u32x4 o = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                                  pack_bf16x2(hi[2], hi[3])};
+                u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]),
+                                  pack2_e<ET>(hi[2], hi[3])};
                 if (a.relu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
@@ -888,7 +926,7 @@ struct TailArgs {
 #ifndef TAIL_AUX
 #define TAIL_AUX 0
 #endif
-template <int C1, bool DS, int NT>
+template <int ET, int C1, bool DS, int NT>
 __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int W3_BYTES = 256 * 128;
@@ -976,10 +1014,10 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
             f32x4 lo = *reinterpret_cast<const f32x4*>(lds + B3_OFF + (32 * t + 8 * fq) * 4);
             f32x4 hi = *reinterpret_cast<const f32x4*>(lds + B3_OFF + (32 * t + 8 * fq + 4) * 4);
             const char* wrow = lds + w3_frag + (2 * t) * 2048;
-            lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + fphys0), xb0, lo, 0, 0, 0);
-            hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + 2048 + fphys0), xb0, hi, 0, 0, 0);
-            lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + (fphys0 ^ 64)), xb1, lo, 0, 0, 0);
-            hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + 2048 + (fphys0 ^ 64)), xb1, hi, 0, 0, 0);
+            lo = mfma_e<ET>(*reinterpret_cast<const bf16x8*>(wrow + fphys0), xb0, lo);
+            hi = mfma_e<ET>(*reinterpret_cast<const bf16x8*>(wrow + 2048 + fphys0), xb0, hi);
+            lo = mfma_e<ET>(*reinterpret_cast<const bf16x8*>(wrow + (fphys0 ^ 64)), xb1, lo);
+            hi = mfma_e<ET>(*reinterpret_cast<const bf16x8*>(wrow + 2048 + (fphys0 ^ 64)), xb1, hi);
             u32x4 r;
             if constexpr (DS) {
                 // identity = bf16(wd . input + bd): rounded exactly as the separate downsample launch stores it
@@ -987,21 +1025,21 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
                 f32x4 dhi = *reinterpret_cast<const f32x4*>(lds + BD_OFF + (32 * t + 8 * fq + 4) * 4);
                 const char* drow = lds + WD_OFF + w3_frag + (2 * t) * 2048;
                 const bf16x8 pb0 = __builtin_bit_cast(bf16x8, rs[0]), pb1 = __builtin_bit_cast(bf16x8, rs[1]);
-                dlo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(drow + fphys0), pb0, dlo, 0, 0, 0);
-                dhi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(drow + 2048 + fphys0), pb0, dhi, 0, 0, 0);
-                dlo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(drow + (fphys0 ^ 64)), pb1, dlo, 0, 0, 0);
-                dhi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(drow + 2048 + (fphys0 ^ 64)), pb1, dhi, 0, 0, 0);
-                r = (u32x4){pack_bf16x2(dlo[0], dlo[1]), pack_bf16x2(dlo[2], dlo[3]), pack_bf16x2(dhi[0], dhi[1]),
-                            pack_bf16x2(dhi[2], dhi[3])};
+                dlo = mfma_e<ET>(*reinterpret_cast<const bf16x8*>(drow + fphys0), pb0, dlo);
+                dhi = mfma_e<ET>(*reinterpret_cast<const bf16x8*>(drow + 2048 + fphys0), pb0, dhi);
+                dlo = mfma_e<ET>(*reinterpret_cast<const bf16x8*>(drow + (fphys0 ^ 64)), pb1, dlo);
+                dhi = mfma_e<ET>(*reinterpret_cast<const bf16x8*>(drow + 2048 + (fphys0 ^ 64)), pb1, dhi);
+                r = (u32x4){pack2_e<ET>(dlo[0], dlo[1]), pack2_e<ET>(dlo[2], dlo[3]), pack2_e<ET>(dhi[0], dhi[1]),
+                            pack2_e<ET>(dhi[2], dhi[3])};
             } else {
                 r = rs[t];
             }
-            lo[0] += bf16_bits_to_f32(r[0] & 0xffffu); lo[1] += __uint_as_float(r[0] & 0xffff0000u);
-            lo[2] += bf16_bits_to_f32(r[1] & 0xffffu); lo[3] += __uint_as_float(r[1] & 0xffff0000u);
-            hi[0] += bf16_bits_to_f32(r[2] & 0xffffu); hi[1] += __uint_as_float(r[2] & 0xffff0000u);
-            hi[2] += bf16_bits_to_f32(r[3] & 0xffffu); hi[3] += __uint_as_float(r[3] & 0xffff0000u);
-            u32x4 o = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                              pack_bf16x2(hi[2], hi[3])};
+            lo[0] += unpack_lo_e<ET>(r[0]); lo[1] += unpack_hi_e<ET>(r[0]);
+            lo[2] += unpack_lo_e<ET>(r[1]); lo[3] += unpack_hi_e<ET>(r[1]);
+            hi[0] += unpack_lo_e<ET>(r[2]); hi[1] += unpack_hi_e<ET>(r[2]);
+            hi[2] += unpack_lo_e<ET>(r[3]); hi[3] += unpack_hi_e<ET>(r[3]);
+            u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]),
+                              pack2_e<ET>(hi[2], hi[3])};
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
             outp[t] = o;
@@ -1027,14 +1065,14 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
 #pragma unroll
             for (int m2 = 0; m2 < M2; ++m2) {
                 const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds + w1_frag + m2 * 8192 + (((4 * t + fq) ^ fr) << 4));
-                acc2[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, kb, acc2[m2], 0, 0, 0);
+                acc2[m2] = mfma_e<ET>(wf, kb, acc2[m2]);
             }
         }
 #pragma unroll
         for (int t2 = 0; t2 < M2 / 2; ++t2) {
             const f32x4 lo = acc2[2 * t2], hi = acc2[2 * t2 + 1];
-            u32x4 o = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                              pack_bf16x2(hi[2], hi[3])};
+            u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]),
+                              pack2_e<ET>(hi[2], hi[3])};
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
             __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, pix * (C1 * 2u) + t2 * 64 + fq * 16, 0, 0);
@@ -1072,6 +1110,7 @@ struct Tail2Args {
 };
 
 #define TAIL2_PF 3      // steps of input prefetch = depth of the unrolled register ring in the step loop
+template <int ET>
 __global__ __launch_bounds__(512) void bneck_tail2_kernel(const Tail2Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int PART_BYTES = 8 * 8 * 1024;                 // [wave][m2] x 1 KiB (f32x4 per lane)
@@ -1145,16 +1184,16 @@ __global__ __launch_bounds__(512) void bneck_tail2_kernel(const Tail2Args a) {
             f32x4 hi = *reinterpret_cast<const f32x4*>(smem + B3_OFF + (cbase + 32 * t + 8 * fq + 4) * 4);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[2 * t][kk], xb[kk], lo, 0, 0, 0);
-                hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[2 * t + 1][kk], xb[kk], hi, 0, 0, 0);
+                lo = mfma_e<ET>(a3[2 * t][kk], xb[kk], lo);
+                hi = mfma_e<ET>(a3[2 * t + 1][kk], xb[kk], hi);
             }
             const u32x4 r = rs[t];
-            lo[0] += bf16_bits_to_f32(r[0] & 0xffffu); lo[1] += __uint_as_float(r[0] & 0xffff0000u);
-            lo[2] += bf16_bits_to_f32(r[1] & 0xffffu); lo[3] += __uint_as_float(r[1] & 0xffff0000u);
-            hi[0] += bf16_bits_to_f32(r[2] & 0xffffu); hi[1] += __uint_as_float(r[2] & 0xffff0000u);
-            hi[2] += bf16_bits_to_f32(r[3] & 0xffffu); hi[3] += __uint_as_float(r[3] & 0xffff0000u);
-            u32x4 o = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                              pack_bf16x2(hi[2], hi[3])};
+            lo[0] += unpack_lo_e<ET>(r[0]); lo[1] += unpack_hi_e<ET>(r[0]);
+            lo[2] += unpack_lo_e<ET>(r[1]); lo[3] += unpack_hi_e<ET>(r[1]);
+            hi[0] += unpack_lo_e<ET>(r[2]); hi[1] += unpack_hi_e<ET>(r[2]);
+            hi[2] += unpack_lo_e<ET>(r[3]); hi[3] += unpack_hi_e<ET>(r[3]);
+            u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]),
+                              pack2_e<ET>(hi[2], hi[3])};
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
             outp[t] = o;
@@ -1172,7 +1211,7 @@ __global__ __launch_bounds__(512) void bneck_tail2_kernel(const Tail2Args a) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[m2][t], __builtin_bit_cast(bf16x8, outp[t]), acc, 0, 0, 0);
+                acc = mfma_e<ET>(a1[m2][t], __builtin_bit_cast(bf16x8, outp[t]), acc);
             *reinterpret_cast<f32x4*>(part + (wave * 8 + m2) * 1024 + lane * 16) = acc;
         }
         // NOT __syncthreads(): that also drains vmcnt, i.e. waits for every prefetch and store in flight
@@ -1186,7 +1225,7 @@ __global__ __launch_bounds__(512) void bneck_tail2_kernel(const Tail2Args a) {
             sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; sum[3] += p[3];
         }
         sum[0] += bias1[0]; sum[1] += bias1[1]; sum[2] += bias1[2]; sum[3] += bias1[3];
-        const unsigned o0 = relu_bf16x2(pack_bf16x2(sum[0], sum[1])), o1 = relu_bf16x2(pack_bf16x2(sum[2], sum[3]));
+        const unsigned o0 = relu_bf16x2(pack2_e<ET>(sum[0], sum[1])), o1 = relu_bf16x2(pack2_e<ET>(sum[2], sum[3]));
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         __builtin_amdgcn_raw_buffer_store_b64((u32x2){o0, o1}, rs_y1, pix * 256u + (16 * wave + 4 * fq) * 2, 0, 0);
     };
@@ -1356,7 +1395,7 @@ __device__ __forceinline__ float frame_value(const unsigned char* p, int c) {
 }
 
 
-template <typename TIN>
+template <int ET, typename TIN>
 __global__ __launch_bounds__(256) void stem_pack_kernel(const TIN* __restrict__ x, u32x2* __restrict__ xp, int n_img) {
     const long long total = (long long)n_img * STEM_HP * STEM_WP;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1370,8 +1409,8 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const TIN* __restrict__ 
         if ((unsigned)hi < 224u && (unsigned)wi < 224u) {
             const TIN* p = x + ((size_t)n * 3 * 224 + hi) * 224 + wi;
             const float c0 = frame_value(p, 0), c1 = frame_value(p + 224 * 224, 1), c2 = frame_value(p + 2 * 224 * 224, 2);
-            o[0] = pack_bf16x2(c0, c1);
-            o[1] = pack_bf16x2(c2, 0.f);
+            o[0] = pack2_e<ET>(c0, c1);
+            o[1] = pack2_e<ET>(c2, 0.f);
         }
         xp[idx] = o;
     }
@@ -1391,6 +1430,7 @@ constexpr int STEM_IN_ROWS = 2 * STEM_ROWS_PER_WG + 5;
 constexpr int STEM_ROW_BYTES = STEM_WP * 8;
 constexpr int STEM_LDS_BYTES = STEM_W_BYTES + STEM_IN_ROWS * STEM_ROW_BYTES;
 
+template <int ET>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const char* __restrict__ xp, const char* __restrict__ wpk,
                                                         const float* __restrict__ bias, __bf16* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1433,7 +1473,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const char* __restrict__
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int j = 0; j < 7; ++j)
-                acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[j], acc[m][j], 0, 0, 0);
+                acc[m][j] = mfma_e<ET>(wf[m], xf[j], acc[m][j]);
     }
 
     const int ho = ho0 + wave;
@@ -1453,7 +1493,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const char* __restrict__
             }
             u32x4 out;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) out[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            for (int e = 0; e < 4; ++e) out[e] = pack2_e<ET>(v[2 * e], v[2 * e + 1]);
             *reinterpret_cast<u32x4*>(y + (((size_t)n * 112 + ho) * 112 + wo) * 64 + cout) = out;
         }
     }
@@ -1463,6 +1503,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const char* __restrict__
 // MaxPool2d(3, stride 2, pad 1), bf16 NHWC.  One thread per (output pixel, 8 channels): nine 16-B
 // loads, fp32 max (padding = -inf), one 16-B store.
 // ------------------------------------------------------------------------------------------------
+template <int ET>
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y,
                                                            int N, int H, int W, int C, int Ho, int Wo) {
     const int cg = C >> 3;
@@ -1488,14 +1529,14 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const __bf16* __restr
                 const u32x4 v = *reinterpret_cast<const u32x4*>(x + (((size_t)n * H + hi) * W + wi) * C + g * 8);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    m[2 * e] = fmaxf(m[2 * e], bf16_bits_to_f32(v[e] & 0xffffu));
-                    m[2 * e + 1] = fmaxf(m[2 * e + 1], bf16_bits_to_f32(v[e] >> 16));
+                    m[2 * e] = fmaxf(m[2 * e], unpack_lo_e<ET>(v[e]));
+                    m[2 * e + 1] = fmaxf(m[2 * e + 1], unpack_hi_e<ET>(v[e]));
                 }
             }
         }
         u32x4 out;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = pack_bf16x2(m[2 * e], m[2 * e + 1]);
+        for (int e = 0; e < 4; ++e) out[e] = pack2_e<ET>(m[2 * e], m[2 * e + 1]);
         *reinterpret_cast<u32x4*>(y + (size_t)idx * 8) = out;
     }
 }
@@ -1504,6 +1545,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const __bf16* __restr
 // Global average pool: (N, HW, C) bf16 -> (N, C) fp32.  One thread per (n, 8 channels); the HW rows
 // are summed in order in fp32 and multiplied by 1/HW.
 // ------------------------------------------------------------------------------------------------
+template <int ET>
 __global__ __launch_bounds__(256) void avgpool_kernel(const __bf16* __restrict__ x, float* __restrict__ y,
                                                       int N, int HW, int C, float inv_hw) {
     const int cg = C >> 3;
@@ -1518,8 +1560,8 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const __bf16* __restrict__
         const u32x4 v = *reinterpret_cast<const u32x4*>(p + (size_t)r * C);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            s[2 * e] += bf16_bits_to_f32(v[e] & 0xffffu);
-            s[2 * e + 1] += bf16_bits_to_f32(v[e] >> 16);
+            s[2 * e] += unpack_lo_e<ET>(v[e]);
+            s[2 * e + 1] += unpack_hi_e<ET>(v[e]);
         }
     }
     float* o = y + (size_t)n * C + g * 8;
@@ -1551,7 +1593,7 @@ __device__ __forceinline__ unsigned max_bf16x2_nonneg(unsigned a, unsigned b) { 
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
 
-template <typename TIN>
+template <int ET, typename TIN>
 __global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const TIN* __restrict__ x, const char* __restrict__ wpk,
                                                                 const float* __restrict__ bias, __bf16* __restrict__ y,
                                                                 int n_tiles, const float* __restrict__ u8_table) {
@@ -1617,7 +1659,7 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const TIN* __res
                 const int row = p_half * SF_PACK_ROWS + r;
                 if (row < SF_IN_ROWS)
                     *reinterpret_cast<u32x2*>(s_in + (row * STEM_WP + p_wp) * 8) =
-                        (u32x2){pack_bf16x2(sample(pc[r][0], 0), sample(pc[r][1], 1)), pack_bf16x2(sample(pc[r][2], 2), 0.f)};
+                        (u32x2){pack2_e<ET>(sample(pc[r][0], 0), sample(pc[r][1], 1)), pack2_e<ET>(sample(pc[r][2], 2), 0.f)};
             }
         }
         __syncthreads();                               // s_in (and, first time, s_w) ready; previous pooling finished
@@ -1643,7 +1685,7 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const TIN* __res
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[j], acc[m][j], 0, 0, 0);
+                    for (int j = 0; j < 7; ++j) acc[m][j] = mfma_e<ET>(wf[m], xf[j], acc[m][j]);
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -1654,10 +1696,10 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const TIN* __res
                 for (int j = 0; j < 7; ++j) {
                     const int wo = 16 * j + fr;
                     u32x4 out;
-                    out[0] = relu_bf16x2(pack_bf16x2(acc[2 * t][j][0] + b_lo[0], acc[2 * t][j][1] + b_lo[1]));
-                    out[1] = relu_bf16x2(pack_bf16x2(acc[2 * t][j][2] + b_lo[2], acc[2 * t][j][3] + b_lo[3]));
-                    out[2] = relu_bf16x2(pack_bf16x2(acc[2 * t + 1][j][0] + b_hi[0], acc[2 * t + 1][j][1] + b_hi[1]));
-                    out[3] = relu_bf16x2(pack_bf16x2(acc[2 * t + 1][j][2] + b_hi[2], acc[2 * t + 1][j][3] + b_hi[3]));
+                    out[0] = relu_bf16x2(pack2_e<ET>(acc[2 * t][j][0] + b_lo[0], acc[2 * t][j][1] + b_lo[1]));
+                    out[1] = relu_bf16x2(pack2_e<ET>(acc[2 * t][j][2] + b_lo[2], acc[2 * t][j][3] + b_lo[3]));
+                    out[2] = relu_bf16x2(pack2_e<ET>(acc[2 * t + 1][j][0] + b_hi[0], acc[2 * t + 1][j][1] + b_hi[1]));
+                    out[3] = relu_bf16x2(pack2_e<ET>(acc[2 * t + 1][j][2] + b_hi[2], acc[2 * t + 1][j][3] + b_hi[3]));
                     *reinterpret_cast<u32x4*>(s_out + (wave * 112 + wo) * 128 + (((4 * t + fq) ^ (wo & 7)) << 4)) = out;
                 }
             }
@@ -1709,14 +1751,15 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const TIN* __res
 // 1/16 of the bf16 rate).
 // ================================================================================================
 __device__ __forceinline__ void split_bf16(float v, unsigned& head16, unsigned& tail16) {
-    const unsigned h = pack_bf16x2(v, 0.f) & 0xffffu;
+    const unsigned h = pack2_e<0>(v, 0.f) & 0xffffu;
     head16 = h;
-    tail16 = pack_bf16x2(v - bf16_bits_to_f32(h), 0.f) & 0xffffu;
+    tail16 = pack2_e<0>(v - bf16_bits_to_f32(h), 0.f) & 0xffffu;
 }
 
 template <typename TIN>
 __global__ __launch_bounds__(256) void stem_pack_split_kernel(const TIN* __restrict__ x, u32x2* __restrict__ xp_head,
                                                               u32x2* __restrict__ xp_tail, int n_img) {
+    constexpr int ET = 0;      // the (head, tail) pair format is bf16-specific
     const long long total = (long long)n_img * STEM_HP * STEM_WP;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -1746,6 +1789,7 @@ constexpr int STEM_SPLIT_LDS_BYTES = 2 * STEM_W_BYTES + 2 * STEM_IN_ROWS * STEM_
 __global__ __launch_bounds__(256) void stem_conv_split_kernel(const char* __restrict__ xp_head, const char* __restrict__ xp_tail,
                                                               const char* __restrict__ w_head, const char* __restrict__ w_tail,
                                                               const float* __restrict__ bias, __bf16* __restrict__ y) {
+    constexpr int ET = 0;      // the (head, tail) pair format is bf16-specific
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IN_BYTES = STEM_IN_ROWS * STEM_ROW_BYTES;
     const int tid = threadIdx.x;
@@ -1788,7 +1832,7 @@ __global__ __launch_bounds__(256) void stem_conv_split_kernel(const char* __rest
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int j = 0; j < 7; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[j], acc[m][j], 0, 0, 0);
+                for (int j = 0; j < 7; ++j) acc[m][j] = mfma_e<ET>(wf[m], xf[j], acc[m][j]);
         }
     }
     const int ho = ho0 + wave;
@@ -1809,8 +1853,8 @@ __global__ __launch_bounds__(256) void stem_conv_split_kernel(const char* __rest
             u32x4 head, tail;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                head[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                tail[e] = pack_bf16x2(v[2 * e] - bf16_bits_to_f32(head[e] & 0xffffu), v[2 * e + 1] - __uint_as_float(head[e] & 0xffff0000u));
+                head[e] = pack2_e<ET>(v[2 * e], v[2 * e + 1]);
+                tail[e] = pack2_e<ET>(v[2 * e] - unpack_lo_e<ET>(head[e]), v[2 * e + 1] - unpack_hi_e<ET>(head[e]));
             }
             __bf16* o = y + (((size_t)n * 112 + ho) * 112 + wo) * 128 + cout;
             *reinterpret_cast<u32x4*>(o) = head;
@@ -1822,6 +1866,7 @@ __global__ __launch_bounds__(256) void stem_conv_split_kernel(const char* __rest
 // MaxPool2d(3,2,1) on [head(C) | tail(C)] pixels: compares head + tail, writes the re-split maximum.
 __global__ __launch_bounds__(256) void maxpool3x3s2_split_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, int N,
                                                                  int H, int W, int C, int Ho, int Wo) {
+    constexpr int ET = 0;      // the (head, tail) pair format is bf16-specific
     const int cg = C >> 3;
     const long long total = (long long)N * Ho * Wo * cg;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1847,16 +1892,16 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_split_kernel(const __bf16* _
                 const u32x4 vt = *reinterpret_cast<const u32x4*>(p + C);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    m[2 * e] = fmaxf(m[2 * e], bf16_bits_to_f32(vh[e] & 0xffffu) + bf16_bits_to_f32(vt[e] & 0xffffu));
-                    m[2 * e + 1] = fmaxf(m[2 * e + 1], __uint_as_float(vh[e] & 0xffff0000u) + __uint_as_float(vt[e] & 0xffff0000u));
+                    m[2 * e] = fmaxf(m[2 * e], unpack_lo_e<ET>(vh[e]) + unpack_lo_e<ET>(vt[e]));
+                    m[2 * e + 1] = fmaxf(m[2 * e + 1], unpack_hi_e<ET>(vh[e]) + unpack_hi_e<ET>(vt[e]));
                 }
             }
         }
         u32x4 head, tail;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            head[e] = pack_bf16x2(m[2 * e], m[2 * e + 1]);
-            tail[e] = pack_bf16x2(m[2 * e] - bf16_bits_to_f32(head[e] & 0xffffu), m[2 * e + 1] - __uint_as_float(head[e] & 0xffff0000u));
+            head[e] = pack2_e<ET>(m[2 * e], m[2 * e + 1]);
+            tail[e] = pack2_e<ET>(m[2 * e] - unpack_lo_e<ET>(head[e]), m[2 * e + 1] - unpack_hi_e<ET>(head[e]));
         }
         __bf16* o = y + (idx / cg) * (2 * C) + g * 8;
         *reinterpret_cast<u32x4*>(o) = head;
@@ -1867,6 +1912,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_split_kernel(const __bf16* _
 // Global average pool on [head(C) | tail(C)] pixels -> (N, C) fp32.
 __global__ __launch_bounds__(256) void avgpool_split_kernel(const __bf16* __restrict__ x, float* __restrict__ y, int N, int HW,
                                                             int C, float inv_hw) {
+    constexpr int ET = 0;      // the (head, tail) pair format is bf16-specific
     const int cg = C >> 3;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * cg) return;
@@ -1880,8 +1926,8 @@ __global__ __launch_bounds__(256) void avgpool_split_kernel(const __bf16* __rest
         const u32x4 vt = *reinterpret_cast<const u32x4*>(p + (size_t)r * 2 * C + C);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            s[2 * e] += bf16_bits_to_f32(vh[e] & 0xffffu) + bf16_bits_to_f32(vt[e] & 0xffffu);
-            s[2 * e + 1] += __uint_as_float(vh[e] & 0xffff0000u) + __uint_as_float(vt[e] & 0xffff0000u);
+            s[2 * e] += unpack_lo_e<ET>(vh[e]) + unpack_lo_e<ET>(vt[e]);
+            s[2 * e + 1] += unpack_hi_e<ET>(vh[e]) + unpack_hi_e<ET>(vt[e]);
         }
     }
     float* o = y + (size_t)n * C + g * 8;

@@ -136,6 +136,24 @@ void fold_bn(const float* w, const float* gamma, const float* beta, const float*
 }
 
 // (cout, cin, k, k) fp32 -> (cout, k, k, cin) bf16
+// fp32 -> IEEE half, round to nearest even, saturating at +-65504 (the kernels' conversion does the same)
+inline uint16_t f32_to_f16_rne(float f) {
+    if (f > 65504.0f) f = 65504.0f;
+    if (f < -65504.0f) f = -65504.0f;
+    const _Float16 hv = (_Float16)f;
+    uint16_t u;
+    std::memcpy(&u, &hv, 2);
+    return u;
+}
+
+void pack_ohwi_f16(const float* wf, int cout, int cin, int ks, std::vector<uint16_t>& out) {
+    out.resize((size_t)cout * ks * ks * cin);
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < ks * ks; ++t)
+                out[((size_t)o * ks * ks + t) * cin + c] = f32_to_f16_rne(wf[((size_t)o * cin + c) * ks * ks + t]);
+}
+
 void pack_ohwi_bf16(const float* wf, int cout, int cin, int ks, std::vector<uint16_t>& out) {
     out.resize((size_t)cout * ks * ks * cin);
     for (int o = 0; o < cout; ++o)
@@ -186,7 +204,7 @@ inline int perm_row_to_cout(int rho) {   // LDS/MFMA row -> channel inside a 32-
 }
 
 // stem: (64,3,7,7) fp32 folded -> [kh][rho][j=0..7][c=0..3] bf16, j = kw + 1, zero elsewhere
-void pack_stem(const float* wf, std::vector<uint16_t>& out, int part = 0) {   // part: 0 = bf16(w), 1 = tail bf16(w - head)
+void pack_stem(const float* wf, std::vector<uint16_t>& out, int part = 0) {   // part: 0 = bf16(w), 1 = tail bf16(w - head), 2 = fp16(w)
     out.assign((size_t)7 * 64 * 32, 0);
     for (int kh = 0; kh < 7; ++kh)
         for (int rho = 0; rho < 64; ++rho) {
@@ -196,7 +214,7 @@ void pack_stem(const float* wf, std::vector<uint16_t>& out, int part = 0) {   //
                 {
                     const float w = wf[(((size_t)o * 3 + c) * 7 + kh) * 7 + kw];
                     const uint16_t hd = f32_to_bf16_rne(w);
-                    out[(((size_t)kh * 64 + rho) * 8 + (kw + 1)) * 4 + c] = part ? f32_to_bf16_rne(w - bf16_to_f32(hd)) : hd;
+                    out[(((size_t)kh * 64 + rho) * 8 + (kw + 1)) * 4 + c] = part == 2 ? f32_to_f16_rne(w) : part ? f32_to_bf16_rne(w - bf16_to_f32(hd)) : hd;
                 }
         }
 }
@@ -226,14 +244,14 @@ FastDiv make_fast_div(unsigned d) {
 constexpr int kPersistBit = 32;
 int g_num_cus = 0;
 
-template <int BC, int BP, int WC, int WP, int NSTAGE, bool SPLIT = false>
+template <int ET, int BC, int BP, int WC, int WP, int NSTAGE, bool SPLIT = false>
 hipError_t launch_igemm_t(ConvArgs a, bool persistent, hipStream_t s) {
     a.n_ctiles = a.Cout / BC;
     a.n_blocks = a.n_ctiles * ((a.M + BP - 1) / BP);
     a.div_ctiles = make_fast_div((unsigned)a.n_ctiles);
     constexpr int kRowsPerPass = WC * WP * 8;
     const size_t lds = (size_t)NSTAGE * (BC + (BP + kRowsPerPass - 1) / kRowsPerPass * kRowsPerPass) * 128;
-    auto kern = igemm_bf16_kernel<BC, BP, WC, WP, NSTAGE, SPLIT>;
+    auto kern = igemm_bf16_kernel<ET, BC, BP, WC, WP, NSTAGE, SPLIT>;
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -277,14 +295,14 @@ constexpr TunedTile kTuned[] = {
 // Role-specialised kernel (loader waves + consumer waves), always one persistent workgroup per CU: tile id + 64
 constexpr int kWsBit = 64;
 
-template <int BC, int BP, int CWC, int CWP, int NLOAD, int NSTAGE>
+template <int ET, int BC, int BP, int CWC, int CWP, int NLOAD, int NSTAGE>
 hipError_t launch_igemm_ws_t(ConvArgs a, hipStream_t s) {
     a.n_ctiles = a.Cout / BC;
     a.n_blocks = a.n_ctiles * ((a.M + BP - 1) / BP);
     a.div_ctiles = make_fast_div((unsigned)a.n_ctiles);
     constexpr int kRowsPerPass = NLOAD * 8;
     const size_t lds = (size_t)NSTAGE * (BC + (BP + kRowsPerPass - 1) / kRowsPerPass * kRowsPerPass) * 128;
-    auto kern = igemm_ws_kernel<BC, BP, CWC, CWP, NLOAD, NSTAGE>;
+    auto kern = igemm_ws_kernel<ET, BC, BP, CWC, CWP, NLOAD, NSTAGE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (g_num_cus == 0) {
@@ -304,10 +322,11 @@ bool is_c64_shape(const ConvArgs& a) {
     return a.ks == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 64 && a.Cout == 64 && a.H == 56 && a.W == 56 && a.res == nullptr &&
            a.x_cstride == 64 && a.y_cstride == 64 && a.Ktot == 576;
 }
+template <int ET>
 hipError_t launch_conv3x3_c64(const ConvArgs& a, hipStream_t s) {
     if (!is_c64_shape(a)) return hipErrorInvalidValue;
     constexpr size_t lds = 9 * 64 * 128 + 2 * 352 * 128;      // 163,840 = all of the CU's LDS
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<ET>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (g_num_cus == 0) {
         int dev = 0;
@@ -316,7 +335,7 @@ hipError_t launch_conv3x3_c64(const ConvArgs& a, hipStream_t s) {
         g_num_cus = prop.multiProcessorCount;
     }
     const int tiles = a.N * 14;
-    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(tiles < g_num_cus ? tiles : g_num_cus), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(conv3x3_c64_kernel<ET>, dim3(tiles < g_num_cus ? tiles : g_num_cus), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -332,39 +351,45 @@ int auto_tile(const ConvArgs& a) {
     return 1;
 }
 
-hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s, bool split = false) {
+template <int ET>
+hipError_t launch_igemm_et(const ConvArgs& a, int tile, hipStream_t s, bool split) {
+    if (split && ET != 0) return hipErrorInvalidValue;
     if (split) {       // fp32-class mode: two tile shapes are enough (it is the accuracy path, not the fast one)
-        if (a.Cout % 128) return launch_igemm_t<64, 128, 1, 4, 2, true>(a, false, s);
-        return launch_igemm_t<128, 128, 2, 2, 2, true>(a, false, s);
+        if (a.Cout % 128) return launch_igemm_t<0, 64, 128, 1, 4, 2, true>(a, false, s);
+        return launch_igemm_t<0, 128, 128, 2, 2, 2, true>(a, false, s);
     }
     if (tile == 0) tile = auto_tile(a);
     const bool pers = (tile & kPersistBit) != 0;
-    if (tile == kTileC64) return launch_conv3x3_c64(a, s);
+    if (tile == kTileC64) return launch_conv3x3_c64<ET>(a, s);
     if (tile & kWsBit) {
         // <couts, pixels, consumer waves (couts x pixels), loader waves, LDS stages>
         switch (tile & (kPersistBit - 1)) {
-            case 1: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_ws_t<128, 128, 2, 2, 4, 4>(a, s);
-            case 3: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_ws_t<256, 128, 4, 2, 4, 3>(a, s);
-            case 4: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_ws_t<128, 224, 2, 2, 4, 3>(a, s);
-            case 8: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_ws_t<128, 224, 4, 2, 4, 3>(a, s);
-            case 9: return launch_igemm_ws_t<64, 224, 2, 2, 4, 4>(a, s);
+            case 1: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_ws_t<ET, 128, 128, 2, 2, 4, 4>(a, s);
+            case 3: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_ws_t<ET, 256, 128, 4, 2, 4, 3>(a, s);
+            case 4: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_ws_t<ET, 128, 224, 2, 2, 4, 3>(a, s);
+            case 8: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_ws_t<ET, 128, 224, 4, 2, 4, 3>(a, s);
+            case 9: return launch_igemm_ws_t<ET, 64, 224, 2, 2, 4, 4>(a, s);
             default: return hipErrorInvalidValue;
         }
     }
     switch (tile & (kPersistBit - 1)) {
-        case 1: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 128, 2, 2, 2>(a, pers, s);
-        case 2: return launch_igemm_t<64, 128, 1, 4, 2>(a, pers, s);
-        case 3: return launch_igemm_t<64, 256, 1, 4, 2>(a, pers, s);
-        case 5: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 64, 2, 2, 2>(a, pers, s);
-        case 6: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 128, 4, 2, 3>(a, pers, s);
-        case 7: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 256, 2, 4, 3>(a, pers, s);
-        case 8: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<128, 128, 2, 4, 3>(a, pers, s);
-        case 9: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 256, 4, 2, 2>(a, pers, s);
-        case 10: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 256, 2, 4, 2>(a, pers, s);
-        case 11: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 208, 8, 1, 2>(a, pers, s);
-        case 12: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<256, 224, 4, 2, 2>(a, pers, s);
+        case 1: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<ET, 128, 128, 2, 2, 2>(a, pers, s);
+        case 2: return launch_igemm_t<ET, 64, 128, 1, 4, 2>(a, pers, s);
+        case 3: return launch_igemm_t<ET, 64, 256, 1, 4, 2>(a, pers, s);
+        case 5: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<ET, 128, 64, 2, 2, 2>(a, pers, s);
+        case 6: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<ET, 256, 128, 4, 2, 3>(a, pers, s);
+        case 7: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<ET, 128, 256, 2, 4, 3>(a, pers, s);
+        case 8: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<ET, 128, 128, 2, 4, 3>(a, pers, s);
+        case 9: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<ET, 256, 256, 4, 2, 2>(a, pers, s);
+        case 10: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<ET, 256, 256, 2, 4, 2>(a, pers, s);
+        case 11: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<ET, 256, 208, 8, 1, 2>(a, pers, s);
+        case 12: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<ET, 256, 224, 4, 2, 2>(a, pers, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s, bool split = false) {
+    return a.et == 1 ? launch_igemm_et<1>(a, tile, s, split) : launch_igemm_et<0>(a, tile, s, split);
 }
 
 int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, const void* wt, const float* bias,
@@ -402,6 +427,7 @@ int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, con
     a.div_howo = make_fast_div((unsigned)a.HoWo);
     a.div_wo = make_fast_div((unsigned)a.Wo);
     a.div_ctiles = FastDiv{0u, 0u};
+    a.et = 0;
 #if defined(R50_STAMP)
     a.dbg = nullptr;
 #endif
@@ -429,15 +455,15 @@ void prof_end(r50_handle* h, hipStream_t s, EvRec& r) {
 
 // conv3 (64 -> 256) + identity + ReLU + next conv1 (256 -> c1) in one launch (kernels.h: bneck_tail_kernel).
 // wd/bd non-null: `res` is the block INPUT (m,64) and the identity is the downsample conv computed in the kernel.
-template <int C1, bool DS, int NT>
+template <int ET, int C1, bool DS, int NT>
 hipError_t launch_bneck_tail_t(const TailArgs& a, hipStream_t s) {
     const size_t lds = 256 * 128 * (DS ? 2 : 1) + (size_t)C1 * 512 + 256 * 4 * (DS ? 2 : 1) + (size_t)C1 * 4;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_tail_kernel<C1, DS, NT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_tail_kernel<ET, C1, DS, NT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const long long tiles = ((long long)a.M + 15) / 16;
     const int grid = (int)std::min<long long>((tiles + NT / 64 - 1) / (NT / 64), (long long)g_num_cus);
-    hipLaunchKernelGGL((bneck_tail_kernel<C1, DS, NT>), dim3(grid), dim3(NT), lds, s, a);
+    hipLaunchKernelGGL((bneck_tail_kernel<ET, C1, DS, NT>), dim3(grid), dim3(NT), lds, s, a);
     return hipGetLastError();
 }
 
@@ -448,7 +474,7 @@ hipError_t launch_bneck_tail_t(const TailArgs& a, hipStream_t s) {
 #define TAIL_NT_C128 256
 #endif
 hipError_t launch_bneck_tail(const void* y2, long long m, const void* w3, const float* b3, const void* res, const void* wd,
-                             const float* bd, void* out, const void* w1, int c1, const float* b1, void* y1n, hipStream_t s) {
+                             const float* bd, void* out, const void* w1, int c1, const float* b1, void* y1n, hipStream_t s, int et = 0) {
     if (!y2 || !w3 || !b3 || !res || !out || !w1 || !b1 || !y1n || m <= 0 || m * 512 >= (1ll << 31)) return hipErrorInvalidValue;
     if ((c1 != 64 && c1 != 128) || ((wd == nullptr) != (bd == nullptr))) return hipErrorInvalidValue;
     TailArgs a;
@@ -462,13 +488,17 @@ hipError_t launch_bneck_tail(const void* y2, long long m, const void* w3, const 
         g_num_cus = prop.multiProcessorCount;
     }
     // 4 waves per CU stream best (more waves lower the HBM rate); the downsample variant has 1.5x the MFMA work
-    if (wd) return c1 == 64 ? launch_bneck_tail_t<64, true, TAIL_NT_DS>(a, s) : launch_bneck_tail_t<128, true, TAIL_NT_DS>(a, s);
-    return c1 == 64 ? launch_bneck_tail_t<64, false, 256>(a, s) : launch_bneck_tail_t<128, false, TAIL_NT_C128>(a, s);
+    if (et == 1) {
+        if (wd) return c1 == 64 ? launch_bneck_tail_t<1, 64, true, TAIL_NT_DS>(a, s) : launch_bneck_tail_t<1, 128, true, TAIL_NT_DS>(a, s);
+        return c1 == 64 ? launch_bneck_tail_t<1, 64, false, 256>(a, s) : launch_bneck_tail_t<1, 128, false, TAIL_NT_C128>(a, s);
+    }
+    if (wd) return c1 == 64 ? launch_bneck_tail_t<0, 64, true, TAIL_NT_DS>(a, s) : launch_bneck_tail_t<0, 128, true, TAIL_NT_DS>(a, s);
+    return c1 == 64 ? launch_bneck_tail_t<0, 64, false, 256>(a, s) : launch_bneck_tail_t<0, 128, false, TAIL_NT_C128>(a, s);
 }
 
 // layer2 shapes: conv3 (128 -> 512) + identity + ReLU + next conv1 (512 -> 128) (kernels.h: bneck_tail2_kernel)
 hipError_t launch_bneck_tail2(const void* y2, long long m, const void* w3, const float* b3, const void* res, void* out,
-                              const void* w1, const float* b1, void* y1n, hipStream_t s) {
+                              const void* w1, const float* b1, void* y1n, hipStream_t s, int et = 0) {
     if (!y2 || !w3 || !b3 || !res || !out || !w1 || !b1 || !y1n || m <= 0 || m * 1024 >= (1ll << 31)) return hipErrorInvalidValue;
     Tail2Args a;
     a.y2 = (const __bf16*)y2; a.w3 = (const __bf16*)w3; a.b3 = b3; a.res = (const __bf16*)res; a.out = (__bf16*)out;
@@ -482,9 +512,10 @@ hipError_t launch_bneck_tail2(const void* y2, long long m, const void* w3, const
     const long long steps = (m + 15) / 16;
     const int grid = (int)std::min<long long>(steps, (long long)g_num_cus);
     const size_t lds = 2 * 8 * 8 * 1024 + 512 * 4 + 2 * 4096;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_tail2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kern = et == 1 ? bneck_tail2_kernel<1> : bneck_tail2_kernel<0>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bneck_tail2_kernel, dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -495,6 +526,7 @@ int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, 
     const bool w2 = (h->precision == R50_PREC_BF16W2);
     int rc = fill_conv_args(a, x, n, hh, ww, L.cin, L.w, L.bias, res, y, L.cout, L.ks, L.stride, L.pad, relu, split, w2);
     if (rc) return fail(h, rc, "conv args invalid for " + L.conv_key);
+    a.et = (h->precision == R50_PREC_FP16) ? 1 : 0;
     EvRec r{};
     const double flops = 2.0 * a.M * (double)a.Cout * L.ks * L.ks * L.cin;       // algorithmic (not the 3x of split mode)
     const double bytes = 2.0 * ((double)n * hh * ww * L.cin + (double)a.M * a.Cout * (res ? 2 : 1) + (double)a.Cout * L.ks * L.ks * L.cin);
@@ -507,27 +539,27 @@ int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, 
 }
 
 template <typename TIN>
-hipError_t launch_stem_pack(const TIN* x, void* xp, int n, hipStream_t s) {
+hipError_t launch_stem_pack(const TIN* x, void* xp, int n, hipStream_t s, int et = 0) {
     const long long total = (long long)n * STEM_HP * STEM_WP;
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
-    hipLaunchKernelGGL(stem_pack_kernel<TIN>, dim3((unsigned)blocks), dim3(256), 0, s, x, (u32x2*)xp, n);
+    if (et == 1) hipLaunchKernelGGL((stem_pack_kernel<1, TIN>), dim3((unsigned)blocks), dim3(256), 0, s, x, (u32x2*)xp, n);
+    else hipLaunchKernelGGL((stem_pack_kernel<0, TIN>), dim3((unsigned)blocks), dim3(256), 0, s, x, (u32x2*)xp, n);
     return hipGetLastError();
 }
-hipError_t launch_stem_conv(const void* xp, const void* wpk, const float* bias, void* y, int n, hipStream_t s) {
-    hipLaunchKernelGGL(stem_conv_kernel, dim3(n * (112 / STEM_ROWS_PER_WG)), dim3(256), STEM_LDS_BYTES, s,
+hipError_t launch_stem_conv(const void* xp, const void* wpk, const float* bias, void* y, int n, hipStream_t s, int et = 0) {
+    auto kern = et == 1 ? stem_conv_kernel<1> : stem_conv_kernel<0>;
+    hipLaunchKernelGGL(kern, dim3(n * (112 / STEM_ROWS_PER_WG)), dim3(256), STEM_LDS_BYTES, s,
                        (const char*)xp, (const char*)wpk, bias, (__bf16*)y);
     return hipGetLastError();
 }
 template <typename TIN>
 hipError_t launch_stem_fused(const TIN* x, const void* wpk, const float* bias, void* y, int n, hipStream_t s,
-                             const float* u8_table) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_kernel<TIN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
+                             const float* u8_table, int et = 0) {
+    auto kern = et == 1 ? stem_fused_kernel<1, TIN> : stem_fused_kernel<0, TIN>;
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr = true;
     }
     if (g_num_cus == 0) {
         int dev = 0;
@@ -537,7 +569,7 @@ hipError_t launch_stem_fused(const TIN* x, const void* wpk, const float* bias, v
     }
     const int tiles = n * 28;
     const int grid = tiles < g_num_cus ? tiles : g_num_cus;       // 128 KB of LDS: one workgroup per CU
-    hipLaunchKernelGGL(stem_fused_kernel<TIN>, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, tiles, u8_table);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, tiles, u8_table);
     return hipGetLastError();
 }
 template <typename TIN>
@@ -571,18 +603,20 @@ hipError_t launch_avgpool_split(const void* x, float* y, int n, int hw, int c, h
                        1.0f / (float)hw);
     return hipGetLastError();
 }
-hipError_t launch_maxpool(const void* x, void* y, int n, int h, int w, int c, hipStream_t s) {
+hipError_t launch_maxpool(const void* x, void* y, int n, int h, int w, int c, hipStream_t s, int et = 0) {
     const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
     const long long total = (long long)n * ho * wo * (c / 8);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)x, (__bf16*)y,
+    auto kern = et == 1 ? maxpool3x3s2_kernel<1> : maxpool3x3s2_kernel<0>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)x, (__bf16*)y,
                        n, h, w, c, ho, wo);
     return hipGetLastError();
 }
-hipError_t launch_avgpool(const void* x, float* y, int n, int hw, int c, hipStream_t s) {
+hipError_t launch_avgpool(const void* x, float* y, int n, int hw, int c, hipStream_t s, int et = 0) {
     const int total = n * (c / 8);
-    hipLaunchKernelGGL(avgpool_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const __bf16*)x, y, n, hw, c,
+    auto kern = et == 1 ? avgpool_kernel<1> : avgpool_kernel<0>;
+    hipLaunchKernelGGL(kern, dim3((total + 255) / 256), dim3(256), 0, s, (const __bf16*)x, y, n, hw, c,
                        1.0f / (float)hw);
     return hipGetLastError();
 }
@@ -595,6 +629,7 @@ int run_stack(r50_handle* h, const TIN* x, int n, float* out, hipStream_t s, con
     // slot0: first frame slot of the workspace this call may use (concurrent calls on different streams
     // work on disjoint frame ranges of the same buffers)
     const bool split = (h->precision == R50_PREC_FP32X);
+    const int et = (h->precision == R50_PREC_FP16) ? 1 : 0;      // element type of weights / activations (kernels.h)
     const int cmul = split ? 2 : 1;            // channels per pixel multiplier of every activation tensor
     __bf16* buf[5];
     for (int i = 0; i < 5; ++i) buf[i] = h->buf[i] + (size_t)slot0 * 112 * 112 * 64 * cmul;
@@ -617,26 +652,26 @@ int run_stack(r50_handle* h, const TIN* x, int n, float* out, hipStream_t s, con
     } else if (h->fused_stem && !(tap && std::string(tap) == "stem")) {
         // conv1 + bn1 + relu + maxpool in one kernel: frame in, (n,56,56,64) out
         prof_begin(h, s, r, PC_STEM_CONV, 2.0 * n * 112 * 112 * 64 * 147.0, (double)n * (3.0 * 224 * 224 * 4 + 56.0 * 56 * 64 * 2));
-        e = launch_stem_fused(x, h->stem_w, h->convs[0].bias, buf[1], n, s, h->u8_table);
+        e = launch_stem_fused(x, h->stem_w, h->convs[0].bias, buf[1], n, s, h->u8_table, et);
         prof_end(h, s, r);
         if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem_fused: ") + hipGetErrorString(e));
         goto after_pool;
     } else {
         prof_begin(h, s, r, PC_STEM_PACK, 0, (double)n * (3.0 * 224 * 224 * 4 + (double)STEM_HP * STEM_WP * 8));
-        e = launch_stem_pack(x, stem_xp, n, s);
+        e = launch_stem_pack(x, stem_xp, n, s, et);
         prof_end(h, s, r);
         if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem_pack: ") + hipGetErrorString(e));
 
         prof_begin(h, s, r, PC_STEM_CONV, 2.0 * n * 112 * 112 * 64 * 147.0,
                    (double)n * ((double)STEM_HP * STEM_WP * 8 + 112.0 * 112 * 64 * 2));
-        e = launch_stem_conv(stem_xp, h->stem_w, h->convs[0].bias, buf[0], n, s);
+        e = launch_stem_conv(stem_xp, h->stem_w, h->convs[0].bias, buf[0], n, s, et);
         prof_end(h, s, r);
         if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem_conv: ") + hipGetErrorString(e));
     }
     if (hit("stem", buf[0], 112, 112, 64)) return R50_OK;
 
     prof_begin(h, s, r, PC_MAXPOOL, 0, (double)n * (112.0 * 112 + 56.0 * 56) * 64 * 2 * cmul);
-    e = split ? launch_maxpool_split(buf[0], buf[1], n, 112, 112, 64, s) : launch_maxpool(buf[0], buf[1], n, 112, 112, 64, s);
+    e = split ? launch_maxpool_split(buf[0], buf[1], n, 112, 112, 64, s) : launch_maxpool(buf[0], buf[1], n, 112, 112, 64, s, et);
     prof_end(h, s, r);
     if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("maxpool: ") + hipGetErrorString(e));
 after_pool:
@@ -666,7 +701,7 @@ after_pool:
             // block the identity (downsample conv of the block input) is computed inside that kernel as well
             const size_t li_next = li + ((b == 0) ? 4 : 3);
             const ConvLayer* nx = (li_next < h->convs.size()) ? &h->convs[li_next] : nullptr;
-            const bool fuse_ok = !split && h->precision == R50_PREC_BF16 && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
+            const bool fuse_ok = !split && (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16) && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
                                  nx->ks == 1 && nx->stride == 1;
             const bool fuse2 = fuse_ok && c3.cin == 128 && c3.cout == 512 && nx->cin == 512 && nx->cout == 128;   // layer2 shapes
             const bool fuse = (fuse_ok && c3.cin == 64 && c3.cout == 256 && nx->cin == 256 && (nx->cout == 64 || nx->cout == 128)) ||
@@ -719,10 +754,10 @@ after_pool:
                                   (double)c3.cout * c3.cin * (fuse_ds ? 2 : 1) + (double)nx->cin * nx->cout),
                            (int)(&c3 - &h->convs[0]));
                 if (fuse2)
-                    e = launch_bneck_tail2(buf[fr[1]], m, c3.w, c3.bias, idn, buf[fr[3]], nx->w, nx->bias, buf[fr[0]], s);
+                    e = launch_bneck_tail2(buf[fr[1]], m, c3.w, c3.bias, idn, buf[fr[3]], nx->w, nx->bias, buf[fr[0]], s, et);
                 else
                     e = launch_bneck_tail(buf[fr[1]], m, c3.w, c3.bias, fuse_ds ? buf[cur] : idn, fuse_ds ? cdp->w : nullptr,
-                                          fuse_ds ? cdp->bias : nullptr, buf[fr[3]], nx->w, nx->cout, nx->bias, buf[fr[0]], s);
+                                          fuse_ds ? cdp->bias : nullptr, buf[fr[3]], nx->w, nx->cout, nx->bias, buf[fr[0]], s, et);
                 prof_end(h, s, rt);
                 if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_tail launch (" + c3.conv_key + "): " + hipGetErrorString(e));
                 h3 = h2; w3 = w2;
@@ -738,7 +773,7 @@ after_pool:
     }
     if (tap) return fail(h, R50_ERR_INVALID, std::string("unknown layer name: ") + tap);
     prof_begin(h, s, r, PC_AVGPOOL, 0, (double)n * (hh * ww * 2048.0 * 2 + 2048.0 * 4));
-    e = split ? launch_avgpool_split(buf[cur], out, n, hh * ww, 2048, s) : launch_avgpool(buf[cur], out, n, hh * ww, 2048, s);
+    e = split ? launch_avgpool_split(buf[cur], out, n, hh * ww, 2048, s) : launch_avgpool(buf[cur], out, n, hh * ww, 2048, s, et);
     prof_end(h, s, r);
     if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("avgpool: ") + hipGetErrorString(e));
     return R50_OK;
@@ -823,7 +858,7 @@ const char* r50_last_error(r50_handle* h) { return h ? h->err.c_str() : g_err.c_
 int r50_create(r50_handle** out, int device_id, int precision, int max_batch) {
     if (!out) return fail(nullptr, R50_ERR_INVALID, "r50_create: out is null");
     *out = nullptr;
-    if (precision != R50_PREC_BF16 && precision != R50_PREC_FP32X && precision != R50_PREC_BF16W2)
+    if (precision != R50_PREC_BF16 && precision != R50_PREC_FP32X && precision != R50_PREC_BF16W2 && precision != R50_PREC_FP16)
         return fail(nullptr, R50_ERR_INVALID, "r50_create: unsupported precision");
     const int cmul = (precision == R50_PREC_FP32X) ? 2 : 1;
     if (max_batch < 1 || max_batch > 1024) return fail(nullptr, R50_ERR_INVALID, "r50_create: max_batch must be in [1,1024]");
@@ -911,7 +946,7 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
         HIP_TRY(h, hipMemcpy(L.bias, bf.data(), L.cout * sizeof(float), hipMemcpyHostToDevice));
         const bool split = (h->precision == R50_PREC_FP32X);
         if (i == 0) {
-            pack_stem(wf.data(), pk, 0);
+            pack_stem(wf.data(), pk, h->precision == R50_PREC_FP16 ? 2 : 0);
             HIP_TRY(h, hipMemcpy(h->stem_w, pk.data(), STEM_W_BYTES, hipMemcpyHostToDevice));
             if (split) {
                 pack_stem(wf.data(), pk, 1);
@@ -920,6 +955,7 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
         } else {
             if (split) pack_ohwi_split(wf.data(), L.cout, L.cin, L.ks, pk);
             else if (h->precision == R50_PREC_BF16W2) pack_ohwi_w2(wf.data(), L.cout, L.cin, L.ks, pk);
+            else if (h->precision == R50_PREC_FP16) pack_ohwi_f16(wf.data(), L.cout, L.cin, L.ks, pk);
             else pack_ohwi_bf16(wf.data(), L.cout, L.cin, L.ks, pk);
             if (!L.w) HIP_TRY(h, hipMalloc((void**)&L.w, pk.size() * 2));
             HIP_TRY(h, hipMemcpy(L.w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));

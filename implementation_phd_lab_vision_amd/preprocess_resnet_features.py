@@ -54,7 +54,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--weights", type=str, default=None, help="Local torchvision resnet50-*.pth (default: seeded synthetic)")
     p.add_argument("--weights-seed", type=int, default=0)
     p.add_argument("--synthetic-clips", type=int, default=0, help="Use N synthetic clips instead of reading --root")
-    p.add_argument("--precision", choices=["bf16", "bf16w2", "fp32x"], default="bf16",
+    p.add_argument("--precision", choices=["bf16", "fp16", "bf16w2", "fp32x"], default="bf16",
                    help="bf16 = the reference's CUDA autocast dtype (fast); fp32x = fp32-class accuracy (its CPU numerics), ~2.7x slower")
     p.add_argument("--micro-batch", type=int, default=0, help="Frames per pass through the layer stack (0 = auto)")
     p.add_argument("--max-batch", type=int, default=256, help="Frames per backbone call chunk (workspace size)")

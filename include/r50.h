@@ -44,10 +44,13 @@ typedef enum r50_precision {
     R50_PREC_FP32X = 2,     /* fp32-class accuracy on the bf16 matrix cores: every value travels as a bf16
                                (head, tail) pair, each conv is three bf16 MFMA products with fp32 accumulation
                                (the reference's CPU numerics, autocast disabled, :239-241; ~3x the bf16 cost) */
-    R50_PREC_BF16W2 = 3     /* bf16 activations, every bottleneck conv weight as a (head, tail) pair of bf16: two MFMA
+    R50_PREC_BF16W2 = 3,    /* bf16 activations, every bottleneck conv weight as a (head, tail) pair of bf16: two MFMA
                                products per conv, one fp32 accumulator, activation traffic as in bf16 mode.  The bf16
                                error of this network is dominated by WEIGHT rounding, so this is enough to bring the
                                features within 1e-3 (rel-L2) of the fp32 reference at about half the fp32x cost */
+    R50_PREC_FP16 = 4       /* IEEE half operands and activations, fp32 MFMA accumulation: the bf16 path with the other
+                               16-bit format (same kernels, same traffic, same speed; conversions saturate at 65504).
+                               11 significand bits instead of 8 put the features 3e-4 from the fp32 reference */
 } r50_precision;
 
 /* One host tensor handed to r50_load_weights: torchvision state-dict key + fp32 data. */

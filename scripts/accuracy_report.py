@@ -1,4 +1,4 @@
-"""Feature accuracy of the three precisions vs the oracle views (8 seeded frames). Run on the GPU box."""
+"""Feature accuracy of the four precisions vs the oracle views (8 seeded frames). Run on the GPU box."""
 import sys, torch
 sys.path.insert(0, '.')
 from implementation_phd_lab_vision_amd import _lib
@@ -14,7 +14,9 @@ print("oracle fp32 vs fp64      : max per-frame rel-L2 %.3e" % float(O.per_row_r
 print("oracle bf16-emu vs fp64  : max per-frame rel-L2 %.3e" % float(O.per_row_rel_l2(emu, f64).max()))
 emu2 = O.forward_bf16_emulated(sd, x, weight_terms=2)
 print("oracle bf16w2-emu vs fp64: max per-frame rel-L2 %.3e" % float(O.per_row_rel_l2(emu2, f64).max()))
-for prec in ("bf16", "bf16w2", "fp32x"):
+emu16 = O.forward_bf16_emulated(sd, x, fmt="fp16")
+print("oracle fp16-emu vs fp64  : max per-frame rel-L2 %.3e" % float(O.per_row_rel_l2(emu16, f64).max()))
+for prec in ("bf16", "fp16", "bf16w2", "fp32x"):
     bb = ResNet50Backbone(state_dict=sd, max_batch=8, precision=prec).to("cuda:0").eval()
     f = bb(x.to("cuda:0")).flatten(1).cpu()
     print(f"device {prec:6s} vs fp64 ref : max per-frame rel-L2 %.3e   max-abs %.3e   (vs bf16-emu oracle %.3e)" %

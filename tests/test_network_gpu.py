@@ -273,3 +273,37 @@ def test_bf16w2_precision_meets_1e3_of_the_fp32_reference(lib_built):
     O.forward_bf16_emulated(sd, x, taps=taps, weight_terms=2)
     t = bb.layer(x.to("cuda:0"), "layer2.1").float().cpu().permute(0, 3, 1, 2)
     assert O.rel_l2(t, taps["layer2.1"]) < 2e-3
+
+
+def test_fp16_precision(lib_built):
+    """fp16 mode: the bf16 path with IEEE half as the 16-bit format (same kernels, MFMA f16).  11 significand bits: the
+    features land ~3e-4 from the fp32/fp64 reference view -- inside north_star's 1e-3 at full speed -- and track the
+    emulation with the same rounding points, taps included (fused stem, resident-weights 3x3, fused tails, plain convs)."""
+    from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
+    from implementation_phd_lab_vision_amd.weights import synthetic_frames, synthetic_state_dict
+    from oracle import resnet50_oracle as O
+    sd = synthetic_state_dict(0)
+    x = synthetic_frames(3, seed=12)
+    bb = ResNet50Backbone(state_dict=sd, max_batch=4, precision="fp16").to("cuda:0").eval()
+    xd = x.to("cuda:0")
+    got = bb.features(xd).cpu()
+    assert torch.isfinite(got).all()
+    ref = O.forward_reference(sd, x, dtype=torch.float64).float()
+    taps = {}
+    emu = O.forward_bf16_emulated(sd, x, taps=taps, fmt="fp16")
+    r_ref, r_emu = O.per_row_rel_l2(got, ref), O.per_row_rel_l2(got, emu)
+    assert float(r_ref.max()) < 1e-3, f"fp16 vs fp64 reference: {r_ref.tolist()}"
+    assert float(r_ref.max()) < 5e-4, f"fp16 should sit well inside the tolerance: {r_ref.tolist()}"
+    assert float(r_emu.max()) < 3e-4, f"fp16 vs its emulation: {r_emu.tolist()}"
+    for name in ["pool", "layer1.0", "layer1.1.t1", "layer1.1.t2", "layer1.2", "layer2.0", "layer2.1.t1", "layer2.3", "layer3.5", "layer4.2"]:
+        t = bb.layer(xd, name)
+        assert t.dtype == torch.float16
+        r = O.rel_l2(t.float().cpu().permute(0, 3, 1, 2), taps[name])
+        assert r < 1e-3, f"{name}: rel-L2 {r} vs the fp16 emulation"
+    # uint8 boundary in fp16 mode: same bits as host-normalised frames
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (2, 3, 224, 224), generator=g, dtype=torch.uint8)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    xn = (u8.to(torch.float32) / 255.0 - mean) / std
+    assert torch.equal(bb.features_u8(u8.to("cuda:0")).cpu(), bb.features(xn.to("cuda:0")).cpu())
