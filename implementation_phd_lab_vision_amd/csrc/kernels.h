@@ -47,8 +47,8 @@ __device__ __forceinline__ unsigned int pack2_e(float lo, float hi) {     // two
     if constexpr (ET == 0) {
         return pack_bf16x2(lo, hi);
     } else {
-        lo = __builtin_fminf(__builtin_fmaxf(lo, -65504.0f), 65504.0f);
-        hi = __builtin_fminf(__builtin_fmaxf(hi, -65504.0f), 65504.0f);
+        lo = __builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f);             // saturate: one v_med3_f32 per value
+        hi = __builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f);
         const f16x2 b = {(_Float16)lo, (_Float16)hi};                   // v_cvt_pk_f16_f32
         return __builtin_bit_cast(unsigned int, b);
     }
