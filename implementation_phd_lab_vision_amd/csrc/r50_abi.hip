@@ -1087,11 +1087,25 @@ static unsigned long long* g_dbg = nullptr;
 extern "C" __attribute__((visibility("default"))) void r50_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
 #endif
 
+static int op_conv2d_et(int et, const void* x, int n, int h, int w, int cin, const void* wt, const float* bias, const void* res,
+                        void* y, int cout, int ksize, int stride, int pad, int relu, int tile, void* stream);
+
 int r50_op_conv2d(const void* x, int n, int h, int w, int cin, const void* wt, const float* bias, const void* res,
                   void* y, int cout, int ksize, int stride, int pad, int relu, int tile, void* stream) {
+    return op_conv2d_et(0, x, n, h, w, cin, wt, bias, res, y, cout, ksize, stride, pad, relu, tile, stream);
+}
+
+int r50_op_conv2d_f16(const void* x, int n, int h, int w, int cin, const void* wt, const float* bias, const void* res,
+                      void* y, int cout, int ksize, int stride, int pad, int relu, int tile, void* stream) {
+    return op_conv2d_et(1, x, n, h, w, cin, wt, bias, res, y, cout, ksize, stride, pad, relu, tile, stream);
+}
+
+static int op_conv2d_et(int et, const void* x, int n, int h, int w, int cin, const void* wt, const float* bias, const void* res,
+                        void* y, int cout, int ksize, int stride, int pad, int relu, int tile, void* stream) {
     ConvArgs a;
     int rc = fill_conv_args(a, x, n, h, w, cin, wt, bias, res, y, cout, ksize, stride, pad, relu);
     if (rc) return fail(nullptr, rc, "r50_op_conv2d: invalid arguments");
+    a.et = et;
 #if defined(R50_STAMP)
     a.dbg = g_dbg;
 #endif

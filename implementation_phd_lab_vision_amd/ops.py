@@ -46,7 +46,10 @@ def conv2d_bf16(x: torch.Tensor, w_ohwi: torch.Tensor, bias: torch.Tensor, strid
     """x (N,H,W,Cin) bf16, w_ohwi (Cout,k,k,Cin) bf16, bias (Cout) fp32 -> (N,Ho,Wo,Cout) bf16.
     ``out``: optional flat bf16 buffer with at least N*Ho*Wo*Cout elements (tests use it to put a
     guard band behind the result)."""
-    _need(x, torch.bfloat16, "x"); _need(w_ohwi, torch.bfloat16, "w"); _need(bias, torch.float32, "bias")
+    et = x.dtype                      # bf16, or fp16 (the R50_PREC_FP16 element type): every tensor in the same format
+    if et not in (torch.bfloat16, torch.float16):
+        raise ValueError("conv2d_bf16: x must be bf16 or fp16")
+    _need(x, et, "x"); _need(w_ohwi, et, "w"); _need(bias, torch.float32, "bias")
     n, h, w, cin = x.shape
     cout, k, k2, cin2 = w_ohwi.shape
     if k != k2 or cin2 != cin or bias.numel() != cout:
@@ -54,19 +57,20 @@ def conv2d_bf16(x: torch.Tensor, w_ohwi: torch.Tensor, bias: torch.Tensor, strid
     ho = (h + 2 * pad - k) // stride + 1
     wo = (w + 2 * pad - k) // stride + 1
     if out is not None:
-        _need(out, torch.bfloat16, "out")
+        _need(out, et, "out")
         if out.numel() < n * ho * wo * cout:
             raise ValueError("conv2d_bf16: out buffer too small")
         y = out.view(-1)[: n * ho * wo * cout].view(n, ho, wo, cout)
     else:
-        y = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=x.device)
+        y = torch.empty((n, ho, wo, cout), dtype=et, device=x.device)
     if residual is not None:
-        _need(residual, torch.bfloat16, "residual")
+        _need(residual, et, "residual")
         if residual.shape != y.shape:
             raise ValueError("conv2d_bf16: residual shape mismatch")
     lib = _lib.load_library()
     with torch.cuda.device(x.device):
-        rc = lib.r50_op_conv2d(x.data_ptr(), n, h, w, cin, w_ohwi.data_ptr(), bias.data_ptr(),
+        fn = lib.r50_op_conv2d if et == torch.bfloat16 else lib.r50_op_conv2d_f16
+        rc = fn(x.data_ptr(), n, h, w, cin, w_ohwi.data_ptr(), bias.data_ptr(),
                                residual.data_ptr() if residual is not None else None, y.data_ptr(),
                                cout, k, stride, pad, int(relu), int(tile), _stream(x))
     _lib.check(rc, None, "r50_op_conv2d")

@@ -129,6 +129,10 @@ const char* r50_version(void);
 int r50_op_conv2d(const void* x_nhwc_bf16, int n, int h, int w, int cin, const void* w_ohwi_bf16,
                   const float* bias_f32, const void* residual_nhwc_bf16, void* y_nhwc_bf16,
                   int cout, int ksize, int stride, int pad, int relu, int tile, void* stream);
+/* The same with IEEE-half tensors (R50_PREC_FP16's element type). */
+int r50_op_conv2d_f16(const void* x_nhwc_f16, int n, int h, int w, int cin, const void* w_ohwi_f16,
+                  const float* bias_f32, const void* residual_nhwc_f16, void* y_nhwc_f16,
+                  int cout, int ksize, int stride, int pad, int relu, int tile, void* stream);
 
 /* Stem: fp32 NCHW frames -> conv 7x7 s2 p3 (+folded bn1 bias) + ReLU -> (n,112,112,64) bf16 NHWC.
  * w_oihw_f32: (64,3,7,7) fp32 *already folded*, host pointer; bias_f32: device pointer (64).
