@@ -926,6 +926,7 @@ struct TailArgs {
 #ifndef TAIL_AUX
 #define TAIL_AUX 0
 #endif
+
 template <int ET, int C1, bool DS, int NT>
 __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -982,10 +983,11 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
     // Inputs of a tile live in ONE register set: as soon as a register has been consumed, the load of the next
     // tile's value is issued into it (a tile takes far longer than a memory round trip, so the in-order vmcnt
     // behind this tile's stores never stalls).
+    constexpr int TAIL_PF = DS ? 1 : 2;  // tiles of input prefetch per wave: two where the inputs are the big identity tensor (-5 %), one in the
+                                         // MFMA-heavier downsample variant (two measured 3 % slower there)
     constexpr int NRS = DS ? 2 : 8;      // identity registers: 8 chunks of the identity itself, or 2 B fragments of the block input
-    u32x4 xf[2], rs[NRS];
     int tile = blockIdx.x * (NT / 64) + wave;
-    {
+    auto first_loads = [&](int tile, u32x4 (&xf)[2], u32x4 (&rs)[NRS]) {
         const unsigned pix = (unsigned)(tile * 16 + fr);           // past M: the descriptor returns zeros
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) xf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_y2, pix * 128u + kk * 64 + fq * 16, 0, 0);
@@ -996,10 +998,12 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix * 512u + t * 64 + fq * 16, 0, TAIL_AUX);
         }
-    }
-    for (; tile < ntiles; tile += nwaves) {
+    };
+    // TAIL_PF register sets, used round robin (loop unrolled by TAIL_PF so they are indexed statically): a set's loads for
+    // tile t + TAIL_PF*nwaves are issued as soon as tile t has consumed it.
+    auto do_tile = [&](int tile, u32x4 (&xf)[2], u32x4 (&rs)[NRS]) {
         const unsigned pix = (unsigned)(tile * 16 + fr);
-        const unsigned pix_n = (unsigned)((tile + nwaves) * 16 + fr);
+        const unsigned pix_n = (unsigned)((tile + TAIL_PF * nwaves) * 16 + fr);
         const bf16x8 xb0 = __builtin_bit_cast(bf16x8, xf[0]), xb1 = __builtin_bit_cast(bf16x8, xf[1]);
         // The weights in LDS never change, so the compiler would hoist all 64+ fragment reads out of the tile
         // loop and spill them; an opaque zero per iteration keeps the reads where they are used.
@@ -1076,6 +1080,16 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
             __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, pix * (C1 * 2u) + t2 * 64 + fq * 16, 0, 0);
+        }
+        };
+    u32x4 xfA[2], rsA[NRS], xfB[2], rsB[NRS];
+    first_loads(tile, xfA, rsA);
+    if (TAIL_PF > 1) first_loads(tile + nwaves, xfB, rsB);
+    while (tile < ntiles) {
+        do_tile(tile, xfA, rsA); tile += nwaves;
+        if (TAIL_PF > 1) {
+            if (tile >= ntiles) break;
+            do_tile(tile, xfB, rsB); tile += nwaves;
         }
     }
 #else
