@@ -339,16 +339,47 @@ hipError_t launch_conv3x3_c64(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// tiles a launch of tile id `tile` would have (0 if the id does not divide this Cout)
+long long tiles_of(const ConvArgs& a, int tile) {
+    int bc = 0, bp = 0;
+    if (tile & kWsBit) {
+        switch (tile & (kPersistBit - 1)) {
+            case 1: bc = 128; bp = 128; break;  case 3: bc = 256; bp = 128; break;  case 4: case 8: bc = 128; bp = 224; break;
+            case 9: bc = 64; bp = 224; break;   default: return 0;
+        }
+    } else {
+        switch (tile & (kPersistBit - 1)) {
+            case 1: case 8: bc = 128; bp = 128; break;  case 2: bc = 64; bp = 128; break;   case 3: bc = 64; bp = 256; break;
+            case 5: bc = 128; bp = 64; break;           case 6: bc = 256; bp = 128; break;  case 7: bc = 128; bp = 256; break;
+            case 9: case 10: bc = 256; bp = 256; break; case 11: bc = 256; bp = 208; break; case 12: bc = 256; bp = 224; break;
+            default: return 0;
+        }
+    }
+    if (a.Cout % bc) return 0;
+    return (long long)(a.Cout / bc) * ((a.M + bp - 1) / bp);
+}
+
 int auto_tile(const ConvArgs& a) {
     if (is_c64_shape(a)) return kTileC64;
+    const long long want = 200;           // of 256 CUs: below that a launch leaves too much of the chip idle
     if (a.N >= 48 && a.H == a.W)
         for (const TunedTile& t : kTuned)
             if (t.h == a.H && t.cin == a.Cin && t.cout == a.Cout && t.ks == a.ks && t.stride == a.stride &&
-                t.res == (a.res != nullptr))
-                return t.tile;
-    if (a.Cout % 128) return 2;
-    if (a.M <= 128 * 128) return 5;       // few pixel tiles: smaller tiles fill more CUs
-    return 1;
+                t.res == (a.res != nullptr)) {
+                // the table was measured at batch 256; a smaller batch may leave its (large) tiles too few to fill the chip
+                if (tiles_of(a, t.tile) >= want) return t.tile;
+                break;
+            }
+    // generic choice: the largest of these tiles that still gives the chip enough workgroups, else the one with the most
+    const int cand[] = {kWsBit | 8, 1, 5, 2};        // 128x224 role-specialised, 128x128, 128x64, 64x128
+    int best = 2;
+    long long best_n = -1;
+    for (int c : cand) {
+        const long long n = tiles_of(a, c);
+        if (n >= want) return c;
+        if (n > best_n) { best_n = n; best = c; }
+    }
+    return best;
 }
 
 template <int ET>
