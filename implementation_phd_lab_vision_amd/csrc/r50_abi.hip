@@ -1212,8 +1212,11 @@ int r50_op_crop_resize_u8(const void* frames, int t, int h, int w, int top, int 
     }
     a.src = (const unsigned char*)frames; a.dst = (unsigned char*)out;
     a.T = t; a.H = h; a.W = w; a.top = top; a.left = left; a.hh = hh; a.ww = ww; a.out = out_size;
-    const long long threads = (long long)t * out_size * (out_size / 4);
-    hipLaunchKernelGGL(crop_resize_u8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    const size_t lds = 2 * (size_t)((ww * 3 + 6) & ~3);                // two source rows of the crop, dword-padded
+    if (lds > 160 * 1024 || (long long)t * out_size >= (1ll << 31)) return fail(nullptr, R50_ERR_INVALID, "r50_op_crop_resize_u8: crop too wide");
+    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(crop_resize_u8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return fail(nullptr, R50_ERR_HIP, std::string("r50_op_crop_resize_u8: ") + hipGetErrorString(ea));
+    hipLaunchKernelGGL(crop_resize_u8_kernel, dim3((unsigned)(t * out_size)), dim3(256), lds, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, R50_ERR_HIP, std::string("r50_op_crop_resize_u8: ") + hipGetErrorString(e));
     return R50_OK;
