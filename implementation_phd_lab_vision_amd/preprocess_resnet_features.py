@@ -30,6 +30,7 @@ import torch
 from torch.utils.data import DataLoader, Subset
 
 from . import distributed as D
+from .prefetch import DevicePrefetcher
 from .shards import AUG_NAMES, AsyncFileWriter, ShardPacker
 
 
@@ -126,8 +127,11 @@ def extract_features(backbone: Callable[[torch.Tensor], torch.Tensor], variants_
     the work) is replaced by a flip.  Only when the frames really are the reverse (checked per batch)."""
     per_variant = []
     for vi, (v_video, *_rest) in enumerate(variants_batch):
+        if v_video is None:                            # the prefetcher found it to be the time reverse and did not upload it
+            per_variant.append(per_variant[0].flip(1))
+            continue
         if (reuse_trev and len(variants_batch) == len(AUG_NAMES) and vi == AUG_NAMES.index("trev")
-                and _is_time_reverse_of(v_video, variants_batch[0][0])):
+                and v_video.device == variants_batch[0][0].device and _is_time_reverse_of(v_video, variants_batch[0][0])):
             per_variant.append(per_variant[0].flip(1))
             continue
         v_video = v_video.to(device, non_blocking=True)
@@ -162,6 +166,9 @@ def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.Ran
             kw["prefetch_factor"] = 2
         loader = DataLoader(Subset(ds, mine) if ctx.distributed else ds, **kw)
     it = iter(loader) if loader is not None else None
+    if it is not None:       # copy batch k+1 to the device on a side stream while batch k computes (no-op on a CPU device)
+        it = DevicePrefetcher(it, device, augment=args.augment, skip_trev=not getattr(args, "no_trev_reuse", False),
+                              trev_index=AUG_NAMES.index("trev"))
 
     packer = None
     if ctx.is_root:
