@@ -219,6 +219,19 @@ def test_conv2d_fp16_matches_oracle(lib_built, case):
         assert float((diff > 0).float().mean()) < 0.01 and rel_l2(got, ref) < 2e-4, f"fp16 conv tile={tile}"
 
 
+def test_conv2d_fp16_saturates_instead_of_overflowing(lib_built):
+    """fp16 mode converts with a clamp at +-65504: an accumulator beyond the half range must come out as the largest
+    finite half, never as infinity (a single inf would poison every later layer)."""
+    from implementation_phd_lab_vision_amd import ops
+    d = _dev()
+    x = torch.full((1, 4, 4, 64), 200.0, dtype=torch.float16, device=d)
+    w = torch.full((64, 1, 1, 64), 30.0, dtype=torch.float16, device=d)          # 64 * 200 * 30 = 384,000 > 65,504
+    w[1::2] = -30.0
+    y = ops.conv2d_bf16(x, w, torch.zeros(64, device=d), relu=False, tile=ops.TILE_64x128)
+    assert torch.isfinite(y).all()
+    assert bool((y[..., 0::2] == 65504.0).all()) and bool((y[..., 1::2] == -65504.0).all())
+
+
 def test_conv2d_identity_asymmetric(lib_built):
     """A = I check with an asymmetric B (cdna guide §3): 1x1 conv with identity weights must return
     the input exactly; a transposed operand or C/D map cannot pass."""
