@@ -1410,6 +1410,99 @@ __global__ __launch_bounds__(256) void crop_resize_u8_kernel(const ResizeArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lifting head (forward only): the non-GEMM pieces of PHDFor3DJoints.forward (src/model.py).  Every
+// Linear and causal conv1d of the head runs on the igemm kernels as a 1x1 convolution over the B*T "pixels":
+// a causal conv1d with kernel 3 and replicate left padding (:20-35) is a GEMM with K = 3*C against the row
+// [x(t-2) | x(t-1) | x(t)] (indices clamped at 0), so the producer of its input writes that row directly.
+// ------------------------------------------------------------------------------------------------
+
+// fp32 rows (rows, c) -> element rows (rows, cpad), columns c..cpad-1 zero (GEMM K must be a multiple of 64)
+template <int ET>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                        long long rows, int c, int cpad) {
+    const long long pairs = rows * (cpad / 2);
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < pairs; i += (long long)gridDim.x * 256) {
+        const long long r = i / (cpad / 2);
+        const int col = (int)(i - r * (cpad / 2)) * 2;
+        const float a = col < c ? src[r * c + col] : 0.f, b = col + 1 < c ? src[r * c + col + 1] : 0.f;
+        *reinterpret_cast<unsigned*>(dst + r * cpad + col) = pack2_e<ET>(a, b);
+    }
+}
+
+// [phi (rows, d) element | y (rows, ny) fp32 | zeros] -> (rows, dp) element: the regressor's input torch.cat([phi, y]) (:113)
+template <int ET>
+__global__ __launch_bounds__(256) void concat_pad_kernel(const unsigned short* __restrict__ phi, int d, const float* __restrict__ y,
+                                                         int ny, unsigned short* __restrict__ dst, long long rows, int dp) {
+    const long long total = rows * dp;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / dp;
+        const int col = (int)(i - r * dp);
+        unsigned short v = 0;
+        if (col < d) v = phi[r * d + col];
+        else if (col < d + ny) v = (unsigned short)(pack2_e<ET>(y[r * ny + (col - d)], 0.f) & 0xffffu);
+        dst[i] = v;
+    }
+}
+
+// y (rows, ny) fp32 += dy (rows, dp) element, first ny columns: `y = y + dy` of the iterative regressor (:114-115); y stays fp32
+template <int ET>
+__global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ y, int ny, const unsigned short* __restrict__ dy, int dp,
+                                                       long long rows) {
+    const long long total = rows * ny;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / ny;
+        const int col = (int)(i - r * ny);
+        y[i] += unpack_lo_e<ET>(dy[r * dp + col]);
+    }
+}
+
+// GroupNorm(groups) + ReLU over x (B, T, C) [channels contiguous], fp32 statistics over the (C/groups x T) slab of one sample
+// and group (biased variance, eps inside the square root: torch.nn.functional.group_norm), then the causal-conv input
+// rows out (B*T, 3C): out[(b,t)][k*C + c] = y[b][max(t-2+k, 0)][c].  One workgroup per (sample, group).
+template <int ET>
+__global__ __launch_bounds__(256) void gn_relu_causal3_kernel(const unsigned short* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, unsigned short* __restrict__ out,
+                                                              int T, int C, int groups, float eps) {
+    __shared__ float red[2][256];
+    const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+    const int cg = C / groups, n = cg * T;
+    const unsigned short* xb = x + (size_t)b * T * C + g * cg;
+    auto ld = [&](int i) -> float {                       // element i of the slab: (t = i / cg, c = i % cg)
+        const int t = i / cg, c = i - t * cg;
+        const unsigned u = xb[(size_t)t * C + c];
+        return ET == 0 ? bf16_bits_to_f32(u) : (float)__builtin_bit_cast(_Float16, (unsigned short)u);
+    };
+    float s = 0.f, ss = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float v = ld(i); s += v; ss += v * v; }
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    const float mean = red[0][0] / (float)n;
+    const float var = fmaxf(red[1][0] / (float)n - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int t = i / cg, c = i - t * cg, ch = g * cg + c;
+        float v = (ld(i) - mean) * rstd * gamma[ch] + beta[ch];
+        v = fmaxf(v, 0.f);
+        const unsigned short e = (unsigned short)(pack2_e<ET>(v, 0.f) & 0xffffu);
+        // y(t) is tap k of row r = t + 2 - k; row 0 also takes y(0) for k = 0, 1 and row 1 for k = 0 (replicate padding)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int r = t + 2 - k;
+            if (r < T) out[((size_t)b * T + r) * 3 * C + k * C + ch] = e;
+        }
+        if (t == 0) {
+            out[((size_t)b * T + 0) * 3 * C + 0 * C + ch] = e;
+            out[((size_t)b * T + 0) * 3 * C + 1 * C + ch] = e;
+            if (T > 1) out[((size_t)b * T + 1) * 3 * C + 0 * C + ch] = e;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stem, step 1: fp32 NCHW (N,3,224,224) -> bf16 "NHWC4" with a zero border:
 //   xp[n][hp][wp][4], hp = hi + 3 in [0,230), wp = wi + 4 in [0,232); channel 3 = 0.
 // One thread per output pixel (8 B).  The border is rewritten every call.

@@ -1222,6 +1222,50 @@ int r50_op_crop_resize_u8(const void* frames, int t, int h, int w, int top, int 
     return R50_OK;
 }
 
+// ---- lifting head pieces (kernels.h: cast_rows_kernel, concat_pad_kernel, gn_relu_causal3_kernel); et: 0 = bf16, 1 = fp16
+int r50_op_cast_rows(const float* src, int64_t rows, int c, void* dst, int cpad, int et, void* stream) {
+    if (!src || !dst || rows < 1 || c < 1 || cpad < c || (cpad & 1) || (et != 0 && et != 1))
+        return fail(nullptr, R50_ERR_INVALID, "r50_op_cast_rows: invalid arguments");
+    const long long pairs = rows * (cpad / 2);
+    const unsigned grid = (unsigned)std::min<long long>((pairs + 255) / 256, 256 * 32);
+    if (et) hipLaunchKernelGGL(cast_rows_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, (long long)rows, c, cpad);
+    else hipLaunchKernelGGL(cast_rows_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, (long long)rows, c, cpad);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? R50_OK : fail(nullptr, R50_ERR_HIP, std::string("r50_op_cast_rows: ") + hipGetErrorString(e));
+}
+
+int r50_op_concat_pad(const void* phi, int d, const float* y, int ny, int64_t rows, void* dst, int dp, int et, void* stream) {
+    if (!phi || !y || !dst || rows < 1 || d < 1 || ny < 0 || dp < d + ny || (et != 0 && et != 1))
+        return fail(nullptr, R50_ERR_INVALID, "r50_op_concat_pad: invalid arguments");
+    const long long total = rows * dp;
+    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
+    if (et) hipLaunchKernelGGL(concat_pad_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)phi, d, y, ny, (unsigned short*)dst, (long long)rows, dp);
+    else hipLaunchKernelGGL(concat_pad_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)phi, d, y, ny, (unsigned short*)dst, (long long)rows, dp);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? R50_OK : fail(nullptr, R50_ERR_HIP, std::string("r50_op_concat_pad: ") + hipGetErrorString(e));
+}
+
+int r50_op_add_rows(float* y, int ny, const void* dy, int dp, int64_t rows, int et, void* stream) {
+    if (!y || !dy || rows < 1 || ny < 1 || dp < ny || (et != 0 && et != 1))
+        return fail(nullptr, R50_ERR_INVALID, "r50_op_add_rows: invalid arguments");
+    const long long total = rows * ny;
+    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
+    if (et) hipLaunchKernelGGL(add_rows_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ny, (const unsigned short*)dy, dp, (long long)rows);
+    else hipLaunchKernelGGL(add_rows_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ny, (const unsigned short*)dy, dp, (long long)rows);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? R50_OK : fail(nullptr, R50_ERR_HIP, std::string("r50_op_add_rows: ") + hipGetErrorString(e));
+}
+
+int r50_op_gn_relu_causal3(const void* x, int b, int t, int c, int groups, const float* gamma, const float* beta, float eps,
+                           void* out, int et, void* stream) {
+    if (!x || !gamma || !beta || !out || b < 1 || t < 1 || c < 1 || groups < 1 || c % groups || (et != 0 && et != 1))
+        return fail(nullptr, R50_ERR_INVALID, "r50_op_gn_relu_causal3: invalid arguments");
+    if (et) hipLaunchKernelGGL(gn_relu_causal3_kernel<1>, dim3((unsigned)(b * groups)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, gamma, beta, (unsigned short*)out, t, c, groups, eps);
+    else hipLaunchKernelGGL(gn_relu_causal3_kernel<0>, dim3((unsigned)(b * groups)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, gamma, beta, (unsigned short*)out, t, c, groups, eps);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? R50_OK : fail(nullptr, R50_ERR_HIP, std::string("r50_op_gn_relu_causal3: ") + hipGetErrorString(e));
+}
+
 int64_t r50_stem_scratch_bytes(int n) { return (int64_t)STEM_W_BYTES + (int64_t)n * STEM_HP * STEM_WP * 8; }
 
 int r50_op_stem(const float* x, int n, const float* w_host, const float* bias_dev, void* scratch, void* y, void* stream) {

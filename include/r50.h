@@ -179,6 +179,22 @@ int r50_op_bneck_tail(const void* y2_bf16, int64_t m, int cmid, const void* w3_b
 int r50_op_crop_resize_u8(const void* frames_thwc_u8, int t, int h, int w, int top, int left, int hh, int ww,
                           void* out_tchw_u8, int out_size, int mode, int flags, void* stream);
 
+/* Lifting head, forward (first step): the non-GEMM pieces of `PHDFor3DJoints.forward` (src/model.py:146-178);
+ * its Linear layers and causal conv1d's run on r50_op_conv2d / r50_op_conv2d_f16 as 1x1 convolutions over the b*t rows.
+ * et: 0 = bf16, 1 = fp16.  All device pointers.
+ *  r50_op_cast_rows: fp32 (rows,c) -> element (rows,cpad), zero columns beyond c (`feats` before `input_proj`, :155).
+ *  r50_op_concat_pad: [phi (rows,d) element | y (rows,ny) fp32 | zeros] -> (rows,dp) element = `torch.cat([phi, y], -1)` of the
+ *    iterative regressor (:113) padded to the GEMM's K granularity.
+ *  r50_op_gn_relu_causal3: x (b,t,c) element -> GroupNorm(groups, eps) + ReLU (`ResidualBlock`, :47-55) -> the input rows of
+ *    the following `CausalConv1d` (kernel 3, replicate left padding, :20-35): out (b*t, 3c), row (b,t) =
+ *    [y(t-2) | y(t-1) | y(t)] with indices clamped at 0.
+ *  r50_op_add_rows: y (rows,ny) fp32 += dy (rows,dp) element, first ny columns (`y = y + dy`, :114-115). */
+int r50_op_cast_rows(const float* src_f32, int64_t rows, int c, void* dst, int cpad, int et, void* stream);
+int r50_op_concat_pad(const void* phi, int d, const float* y_f32, int ny, int64_t rows, void* dst, int dp, int et, void* stream);
+int r50_op_add_rows(float* y_f32, int ny, const void* dy, int dp, int64_t rows, int et, void* stream);
+int r50_op_gn_relu_causal3(const void* x, int b, int t, int c, int groups, const float* gamma, const float* beta, float eps,
+                           void* out, int et, void* stream);
+
 /* AdaptiveAvgPool2d((1,1)) + flatten(1): (n,hw,c) bf16 -> (n,c) fp32; c % 8 == 0. */
 int r50_op_avgpool(const void* x_nhwc_bf16, int n, int hw, int c, float* y_f32, void* stream);
 
