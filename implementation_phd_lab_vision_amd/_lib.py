@@ -79,6 +79,19 @@ _SIGNATURES = {
     "r50_op_add_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "r50_op_gn_relu_causal3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                          C.c_void_p, C.c_int, C.c_void_p]),
+    "r50_op_transpose16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "r50_op_mask_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int, C.c_void_p]),
+    "r50_op_relu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int, C.c_void_p]),
+    "r50_op_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "r50_op_colsum_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "r50_op_grad_accum": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "r50_op_mse_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "r50_op_gn_relu_causal3_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "r50_op_check_finite": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "r50_op_check_overflow16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+    "r50_op_adamw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
+                               C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "r50_op_avgpool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 

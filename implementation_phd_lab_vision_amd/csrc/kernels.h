@@ -1503,6 +1503,225 @@ __global__ __launch_bounds__(256) void gn_relu_causal3_kernel(const unsigned sho
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lifting head, backward + optimizer (the training step of src/train.py:137-176).  Every matrix product of
+// the backward pass (dX = dY W, dW = dY^T X) is again an igemm launch (operands transposed by transpose16_kernel so that
+// both are K-contiguous); what follows are the byte-moving pieces around them.
+// ------------------------------------------------------------------------------------------------
+template <int ET>
+__device__ __forceinline__ float ld_e(const unsigned short* p) { return unpack_lo_e<ET>((unsigned)*p); }
+template <int ET>
+__device__ __forceinline__ unsigned short st_e(float v) { return (unsigned short)(pack2_e<ET>(v, 0.f) & 0xffffu); }
+
+// src (rows, cols) 16-bit -> dst (cols, ld) with dst[c][r] = src[r][c]; ld >= rows, columns rows..ld-1 of dst are not written
+__global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
+                                                          int rows, int cols, int ld) {
+    __shared__ unsigned short tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(size_t)(r0 + r) * cols + c0 + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (c0 + c < cols && r0 + r < rows) dst[(size_t)(c0 + c) * ld + r0 + r] = tile[r][c];
+    }
+}
+
+// x *= mask * scale (dropout, src/model.py:44,52,98): mask is one byte per element
+template <int ET>
+__global__ __launch_bounds__(256) void mask_scale_kernel(unsigned short* __restrict__ x, const unsigned char* __restrict__ mask,
+                                                         float scale, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        x[i] = mask[i] ? st_e<ET>(ld_e<ET>(x + i) * scale) : (unsigned short)0;
+}
+
+// dx = dy * scale * (act > 0), in place: backward of ReLU (scale 1) or of ReLU followed by dropout (act = the dropped-out
+// activation, scale = 1/(1-p): it is positive exactly where the ReLU passed AND the mask kept)
+template <int ET>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(unsigned short* __restrict__ dy, const unsigned short* __restrict__ act,
+                                                       float scale, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dy[i] = ld_e<ET>(act + i) > 0.f ? st_e<ET>(ld_e<ET>(dy + i) * scale) : (unsigned short)0;
+}
+
+// out (cols) fp32 [+]= scale * sum over rows of x (rows, ld)[:, :cols]: bias gradients.  One thread per column, rows in order.
+template <int ET>
+__global__ __launch_bounds__(64) void colsum_kernel(const unsigned short* __restrict__ x, long long rows, int cols, int ld,
+                                                    float scale, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (long long r = 0; r < rows; ++r) s += ld_e<ET>(x + r * ld + c);
+    out[c] = (accumulate ? out[c] : 0.f) + s * scale;
+}
+__global__ __launch_bounds__(64) void colsum_f32_kernel(const float* __restrict__ x, long long rows, int cols, float scale,
+                                                        float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (long long r = 0; r < rows; ++r) s += x[r * cols + c];
+    out[c] = (accumulate ? out[c] : 0.f) + s * scale;
+}
+
+// dst (n) fp32 [+]= scale * src (n) 16-bit: a weight gradient out of the GEMM into the flat fp32 gradient buffer
+template <int ET>
+__global__ __launch_bounds__(256) void grad_accum_kernel(const unsigned short* __restrict__ src, float scale, float* __restrict__ dst,
+                                                         long long n, int accumulate) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dst[i] = (accumulate ? dst[i] : 0.f) + ld_e<ET>(src + i) * scale;
+}
+
+// l3d = mean((y - gt)^2) (src/train.py:161): dy = 2 * (y - gt) / n * loss_scale; loss[0] = the mean, loss[1] = sum over
+// joints of |y - gt|_2 / (n/3) = MPJPE (:42-45).  One workgroup (n = B*T*51 is small), fixed summation order.
+__global__ __launch_bounds__(256) void mse_loss_grad_kernel(const float* __restrict__ y, const float* __restrict__ gt, long long n,
+                                                            float loss_scale, float* __restrict__ dy, float* __restrict__ loss) {
+    __shared__ float red[2][256];
+    float s = 0.f, e = 0.f;
+    for (long long j = threadIdx.x; j < n / 3; j += 256) {
+        float d2 = 0.f;
+        for (int k = 0; k < 3; ++k) {
+            const float d = y[3 * j + k] - gt[3 * j + k];
+            dy[3 * j + k] = 2.f * d / (float)n * loss_scale;
+            d2 += d * d;
+        }
+        s += d2; e += sqrtf(d2);
+    }
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = e;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { loss[0] = red[0][0] / (float)n; loss[1] = red[1][0] / (float)(n / 3); }
+}
+
+// Backward of gn_relu_causal3_kernel.  dr (B*T, 3C): gradient of the causal-conv input rows; x (B, T, C): the GroupNorm input
+// saved by the forward.  da(s, c) = sum of dr over the (row, tap) pairs that read frame s (replicate padding: frame 0 also
+// collects the clamped taps), dy = da * (y > 0), and with xh = (x - mean) * rstd, g = dy * gamma over the (C/groups x T) slab:
+//   dx = rstd * (g - mean(g) - xh * mean(g * xh))   [+ add (B, T, C): the residual path's gradient]
+//   dgamma_part[b][c] = sum_t dy * xh, dbeta_part[b][c] = sum_t dy        (per sample; summed over b by colsum_f32_kernel)
+// One workgroup per (sample, group); statistics recomputed from x exactly as the forward computed them.
+template <int ET>
+__global__ __launch_bounds__(256) void gn_relu_causal3_bwd_kernel(const unsigned short* __restrict__ dr, const unsigned short* __restrict__ x,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const unsigned short* __restrict__ add, unsigned short* __restrict__ dx,
+                                                                  float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
+                                                                  int T, int C, int groups, float eps) {
+    __shared__ float red[2][256];
+    __shared__ float cacc[2][256];            // per-channel sums (cg <= 256)
+    const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+    const int cg = C / groups, n = cg * T;
+    const unsigned short* xb = x + (size_t)b * T * C + g * cg;
+    auto block_sum2 = [&](float a, float c2, float& oa, float& oc) {
+        red[0][threadIdx.x] = a; red[1][threadIdx.x] = c2;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+            __syncthreads();
+        }
+        oa = red[0][0]; oc = red[1][0];
+        __syncthreads();
+    };
+    float s = 0.f, ss = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const int t = i / cg, c = i - t * cg; const float v = ld_e<ET>(xb + (size_t)t * C + c); s += v; ss += v * v; }
+    float S, SS;
+    block_sum2(s, ss, S, SS);
+    const float mean = S / (float)n;
+    const float var = fmaxf(SS / (float)n - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    auto dy_of = [&](int t, int c, float& xh) -> float {       // dy and xh of slab element (t, c)
+        const int ch = g * cg + c;
+        xh = (ld_e<ET>(xb + (size_t)t * C + c) - mean) * rstd;
+        if (xh * gamma[ch] + beta[ch] <= 0.f) return 0.f;
+        const unsigned short* row = dr + (size_t)b * T * 3 * C;
+        float da = 0.f;
+        for (int k = 0; k < 3; ++k) {
+            const int r = t + 2 - k;
+            if (r < T) da += ld_e<ET>(row + (size_t)r * 3 * C + k * C + ch);
+        }
+        if (t == 0) {
+            da += ld_e<ET>(row + 0 * C + ch) + ld_e<ET>(row + 1 * C + ch);
+            if (T > 1) da += ld_e<ET>(row + (size_t)1 * 3 * C + 0 * C + ch);
+        }
+        return da;
+    };
+    if ((int)threadIdx.x < cg) { cacc[0][threadIdx.x] = 0.f; cacc[1][threadIdx.x] = 0.f; }
+    __syncthreads();
+    float sg = 0.f, sgx = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int t = i / cg, c = i - t * cg;
+        float xh;
+        const float dy = dy_of(t, c, xh);
+        const float gg = dy * gamma[g * cg + c];
+        sg += gg; sgx += gg * xh;
+    }
+    float SG, SGX;
+    block_sum2(sg, sgx, SG, SGX);
+    const float mg = SG / (float)n, mgx = SGX / (float)n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int t = i / cg, c = i - t * cg;
+        float xh;
+        const float dy = dy_of(t, c, xh);
+        float v = rstd * (dy * gamma[g * cg + c] - mg - xh * mgx);
+        const size_t o = ((size_t)b * T + t) * C + g * cg + c;
+        if (add) v += ld_e<ET>(add + o);
+        dx[o] = st_e<ET>(v);
+    }
+    // per-channel parameter gradients, summed over t in order by one thread per channel
+    for (int c = threadIdx.x; c < cg; c += 256) {
+        float a = 0.f, bb = 0.f;
+        for (int t = 0; t < T; ++t) { float xh; const float dy = dy_of(t, c, xh); a += dy * xh; bb += dy; }
+        dgamma_part[(size_t)b * C + g * cg + c] = a;
+        dbeta_part[(size_t)b * C + g * cg + c] = bb;
+    }
+}
+
+// found[0] = 1 if any of g (n) is not finite (GradScaler's inf check, src/train.py:172-174)
+__global__ __launch_bounds__(256) void check_finite_kernel(const float* __restrict__ g, long long n, int* __restrict__ found) {
+    int bad = 0;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned u = __float_as_uint(g[i]);
+        bad |= ((u & 0x7f800000u) == 0x7f800000u);
+    }
+    if (bad) atomicOr(found, 1);
+}
+
+// found[0] = 1 if any 16-bit element of x is inf / nan or, for IEEE half, at the largest finite magnitude: this build's fp32 -> fp16
+// conversion SATURATES at +-65504 instead of producing inf, so a saturated value is what an overflow looks like
+template <int ET>
+__global__ __launch_bounds__(256) void check_overflow16_kernel(const unsigned short* __restrict__ x, long long n, int* __restrict__ found) {
+    int bad = 0;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned u = x[i] & 0x7fffu;
+        bad |= ET == 1 ? (u >= 0x7bffu) : ((u & 0x7f80u) == 0x7f80u);
+    }
+    if (bad) atomicOr(found, 1);
+}
+
+// torch.optim.AdamW (src/train.py:389; amsgrad off, maximize off) over flat fp32 buffers, skipped when found[0] != 0:
+//   p *= 1 - lr * wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+// and the refreshed 16-bit copy of the parameter the GEMMs read.
+template <int ET>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                    const float* __restrict__ g, unsigned short* __restrict__ p16, long long n,
+                                                    float lr, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2,
+                                                    const int* __restrict__ found) {
+    if (found && found[0]) return;
+    const float step_size = lr / bc1;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i];
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+        pi -= step_size * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        p16[i] = st_e<ET>(pi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stem, step 1: fp32 NCHW (N,3,224,224) -> bf16 "NHWC4" with a zero border:
 //   xp[n][hp][wp][4], hp = hi + 3 in [0,230), wp = wi + 4 in [0,232); channel 3 = 0.
 // One thread per output pixel (8 B).  The border is rewritten every call.

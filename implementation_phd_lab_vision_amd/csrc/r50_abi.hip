@@ -1266,6 +1266,93 @@ int r50_op_gn_relu_causal3(const void* x, int b, int t, int c, int groups, const
     return e == hipSuccess ? R50_OK : fail(nullptr, R50_ERR_HIP, std::string("r50_op_gn_relu_causal3: ") + hipGetErrorString(e));
 }
 
+// ---- lifting head, backward + optimizer (kernels.h, "Lifting head, backward + optimizer") ----
+static unsigned ew_grid(long long n) { return (unsigned)std::min<long long>(std::max<long long>((n + 255) / 256, 1), 256 * 32); }
+static int ew_done(const char* what) {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? R50_OK : fail(nullptr, R50_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define R50_ET_LAUNCH(kern, grid, block, stream, ...)                                                              \
+    do {                                                                                                           \
+        if (et) hipLaunchKernelGGL(kern<1>, grid, block, 0, (hipStream_t)stream, __VA_ARGS__);                      \
+        else hipLaunchKernelGGL(kern<0>, grid, block, 0, (hipStream_t)stream, __VA_ARGS__);                         \
+    } while (0)
+
+int r50_op_transpose16(const void* src, int rows, int cols, void* dst, int ld, void* stream) {
+    if (!src || !dst || rows < 1 || cols < 1 || ld < rows) return fail(nullptr, R50_ERR_INVALID, "r50_op_transpose16: invalid arguments");
+    hipLaunchKernelGGL(transpose16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)src, (unsigned short*)dst, rows, cols, ld);
+    return ew_done("r50_op_transpose16");
+}
+
+int r50_op_mask_scale(void* x, const void* mask_u8, float scale, int64_t n, int et, void* stream) {
+    if (!x || !mask_u8 || n < 1 || (et != 0 && et != 1)) return fail(nullptr, R50_ERR_INVALID, "r50_op_mask_scale: invalid arguments");
+    R50_ET_LAUNCH(mask_scale_kernel, dim3(ew_grid(n)), dim3(256), stream, (unsigned short*)x, (const unsigned char*)mask_u8, scale, (long long)n);
+    return ew_done("r50_op_mask_scale");
+}
+
+int r50_op_relu_bwd(void* dy, const void* act, float scale, int64_t n, int et, void* stream) {
+    if (!dy || !act || n < 1 || (et != 0 && et != 1)) return fail(nullptr, R50_ERR_INVALID, "r50_op_relu_bwd: invalid arguments");
+    R50_ET_LAUNCH(relu_bwd_kernel, dim3(ew_grid(n)), dim3(256), stream, (unsigned short*)dy, (const unsigned short*)act, scale, (long long)n);
+    return ew_done("r50_op_relu_bwd");
+}
+
+int r50_op_colsum(const void* x, int64_t rows, int cols, int ld, float scale, float* out, int accumulate, int et, void* stream) {
+    if (!x || !out || rows < 1 || cols < 1 || ld < cols || (et != 0 && et != 1)) return fail(nullptr, R50_ERR_INVALID, "r50_op_colsum: invalid arguments");
+    R50_ET_LAUNCH(colsum_kernel, dim3((cols + 63) / 64), dim3(64), stream, (const unsigned short*)x, (long long)rows, cols, ld, scale, out, accumulate);
+    return ew_done("r50_op_colsum");
+}
+
+int r50_op_colsum_f32(const float* x, int64_t rows, int cols, float scale, float* out, int accumulate, void* stream) {
+    if (!x || !out || rows < 1 || cols < 1) return fail(nullptr, R50_ERR_INVALID, "r50_op_colsum_f32: invalid arguments");
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, (long long)rows, cols, scale, out, accumulate);
+    return ew_done("r50_op_colsum_f32");
+}
+
+int r50_op_grad_accum(const void* src, float scale, float* dst, int64_t n, int accumulate, int et, void* stream) {
+    if (!src || !dst || n < 1 || (et != 0 && et != 1)) return fail(nullptr, R50_ERR_INVALID, "r50_op_grad_accum: invalid arguments");
+    R50_ET_LAUNCH(grad_accum_kernel, dim3(ew_grid(n)), dim3(256), stream, (const unsigned short*)src, scale, dst, (long long)n, accumulate);
+    return ew_done("r50_op_grad_accum");
+}
+
+int r50_op_mse_loss_grad(const float* y, const float* gt, int64_t n, float loss_scale, float* dy, float* loss2, void* stream) {
+    if (!y || !gt || !dy || !loss2 || n < 3 || n % 3) return fail(nullptr, R50_ERR_INVALID, "r50_op_mse_loss_grad: invalid arguments");
+    hipLaunchKernelGGL(mse_loss_grad_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, y, gt, (long long)n, loss_scale, dy, loss2);
+    return ew_done("r50_op_mse_loss_grad");
+}
+
+int r50_op_gn_relu_causal3_bwd(const void* dr, const void* x, int b, int t, int c, int groups, const float* gamma, const float* beta,
+                               float eps, const void* add, void* dx, float* dgamma_part, float* dbeta_part, int et, void* stream) {
+    if (!dr || !x || !gamma || !beta || !dx || !dgamma_part || !dbeta_part || b < 1 || t < 1 || c < 1 || groups < 1 || c % groups ||
+        c / groups > 256 || (et != 0 && et != 1))
+        return fail(nullptr, R50_ERR_INVALID, "r50_op_gn_relu_causal3_bwd: invalid arguments");
+    R50_ET_LAUNCH(gn_relu_causal3_bwd_kernel, dim3((unsigned)(b * groups)), dim3(256), stream, (const unsigned short*)dr,
+                  (const unsigned short*)x, gamma, beta, (const unsigned short*)add, (unsigned short*)dx, dgamma_part, dbeta_part, t, c,
+                  groups, eps);
+    return ew_done("r50_op_gn_relu_causal3_bwd");
+}
+
+int r50_op_check_finite(const float* g, int64_t n, int* found, void* stream) {
+    if (!g || !found || n < 1) return fail(nullptr, R50_ERR_INVALID, "r50_op_check_finite: invalid arguments");
+    hipLaunchKernelGGL(check_finite_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, g, (long long)n, found);
+    return ew_done("r50_op_check_finite");
+}
+
+int r50_op_check_overflow16(const void* x, int64_t n, int* found, int et, void* stream) {
+    if (!x || !found || n < 1 || (et != 0 && et != 1)) return fail(nullptr, R50_ERR_INVALID, "r50_op_check_overflow16: invalid arguments");
+    R50_ET_LAUNCH(check_overflow16_kernel, dim3(ew_grid(n)), dim3(256), stream, (const unsigned short*)x, (long long)n, found);
+    return ew_done("r50_op_check_overflow16");
+}
+
+int r50_op_adamw(float* p, float* m, float* v, const float* g, void* p16, int64_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, const int* found_inf, int et, void* stream) {
+    if (!p || !m || !v || !g || !p16 || n < 1 || step < 1 || (et != 0 && et != 1)) return fail(nullptr, R50_ERR_INVALID, "r50_op_adamw: invalid arguments");
+    const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+    R50_ET_LAUNCH(adamw_kernel, dim3(ew_grid(n)), dim3(256), stream, p, m, v, g, (unsigned short*)p16, (long long)n, lr, beta1, beta2, eps,
+                  weight_decay, (float)bc1, (float)std::sqrt(bc2), found_inf);
+    return ew_done("r50_op_adamw");
+}
+
 int64_t r50_stem_scratch_bytes(int n) { return (int64_t)STEM_W_BYTES + (int64_t)n * STEM_HP * STEM_WP * 8; }
 
 int r50_op_stem(const float* x, int n, const float* w_host, const float* bias_dev, void* scratch, void* y, void* stream) {

@@ -195,6 +195,36 @@ int r50_op_add_rows(float* y_f32, int ny, const void* dy, int dp, int64_t rows, 
 int r50_op_gn_relu_causal3(const void* x, int b, int t, int c, int groups, const float* gamma, const float* beta, float eps,
                            void* out, int et, void* stream);
 
+/* Lifting head, backward + optimizer: the training step of `train()` (src/train.py:137-176: fp16 autocast forward, `l3d` MSE
+ * loss, GradScaler, AdamW).  Every matrix product of the backward pass (dX = dY W, dW = dY^T X) is an r50_op_conv2d(_f16) launch
+ * on operands transposed by r50_op_transpose16; these are the pieces around them.  16-bit tensors are `et` elements (0 bf16, 1 fp16).
+ *  r50_op_transpose16: src (rows,cols) -> dst (cols,ld), dst[c][r] = src[r][c]; ld >= rows, the padding columns are left alone.
+ *  r50_op_mask_scale: x *= mask * scale in place (`nn.Dropout`, src/model.py:44,98); mask one byte per element.
+ *  r50_op_relu_bwd: dy = dy * scale * (act > 0) in place (backward of ReLU, or of ReLU + dropout with act = the dropped-out tensor).
+ *  r50_op_colsum / _f32: out (cols) fp32 [+]= scale * column sums of x (rows,ld)[:, :cols] (bias gradients; rows summed in order).
+ *  r50_op_grad_accum: dst (n) fp32 [+]= scale * src (n) 16-bit (a weight gradient into the flat fp32 gradient buffer, unscaled).
+ *  r50_op_mse_loss_grad: loss2[0] = mean((y-gt)^2) (:161), loss2[1] = MPJPE (:42-45); dy = 2 (y-gt) / n * loss_scale; n = B*T*J*3.
+ *  r50_op_gn_relu_causal3_bwd: backward of r50_op_gn_relu_causal3: dr (b*t,3c) -> dx (b,t,c) [+ add], per-sample parameter
+ *    gradient parts dgamma_part / dbeta_part (b,c) fp32 (sum over b with r50_op_colsum_f32).
+ *  r50_op_check_finite: found[0] |= any non-finite in g (GradScaler's inf check, :172-174).
+ *  r50_op_check_overflow16: found[0] |= any inf / nan in 16-bit x -- or, for fp16, any element at +-65504: the fp32 -> fp16 conversion
+ *    of this library saturates instead of producing inf, so that is what an overflowed gradient looks like.
+ *  r50_op_adamw: `torch.optim.AdamW` (:389) over flat fp32 p / m / v / g, step >= 1; skipped when found_inf[0] != 0; p16 = the
+ *    refreshed 16-bit copy of p the GEMMs read. */
+int r50_op_transpose16(const void* src, int rows, int cols, void* dst, int ld, void* stream);
+int r50_op_mask_scale(void* x, const void* mask_u8, float scale, int64_t n, int et, void* stream);
+int r50_op_relu_bwd(void* dy, const void* act, float scale, int64_t n, int et, void* stream);
+int r50_op_colsum(const void* x, int64_t rows, int cols, int ld, float scale, float* out_f32, int accumulate, int et, void* stream);
+int r50_op_colsum_f32(const float* x, int64_t rows, int cols, float scale, float* out_f32, int accumulate, void* stream);
+int r50_op_grad_accum(const void* src, float scale, float* dst_f32, int64_t n, int accumulate, int et, void* stream);
+int r50_op_mse_loss_grad(const float* y, const float* gt, int64_t n, float loss_scale, float* dy, float* loss2, void* stream);
+int r50_op_gn_relu_causal3_bwd(const void* dr, const void* x, int b, int t, int c, int groups, const float* gamma, const float* beta,
+                               float eps, const void* add, void* dx, float* dgamma_part, float* dbeta_part, int et, void* stream);
+int r50_op_check_finite(const float* g, int64_t n, int* found, void* stream);
+int r50_op_check_overflow16(const void* x, int64_t n, int* found, int et, void* stream);
+int r50_op_adamw(float* p, float* m, float* v, const float* g, void* p16, int64_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, const int* found_inf, int et, void* stream);
+
 /* AdaptiveAvgPool2d((1,1)) + flatten(1): (n,hw,c) bf16 -> (n,c) fp32; c % 8 == 0. */
 int r50_op_avgpool(const void* x_nhwc_bf16, int n, int hw, int c, float* y_f32, void* stream);
 

@@ -94,3 +94,58 @@ def synthetic_head_state_dict(latent_dim: int = 1024, number_blocks: int = 2, se
     sd["f_3D.mlp.5.weight"] = rnd(51, 1024, scale=(1.0 / 1024) ** 0.5)
     sd["f_3D.mlp.5.bias"] = rnd(51, scale=0.05)
     return sd
+
+
+# ---- training step (src/train.py:137-176, 370-393): CPU restatement with torch autograd, fp32 / fp64 ----------------------
+TRAINABLE_PREFIXES = ("input_proj.", "f_movie.", "f_3D.mlp.")        # f_AR frozen (:375-376); y0 is a buffer
+
+
+def _forward_train(p: Dict[str, torch.Tensor], feats: torch.Tensor, masks: Optional[Dict[str, torch.Tensor]], keep: float = 0.5):
+    """joints_phi of ``PHDFor3DJoints.forward`` in train mode with the dropout keep-masks given explicitly (None: identity).
+    masks: "f_movie.blocks.i" (B*T, D) after conv1 (src/model.py:52), "f_3D.i" (B*T, 1024) after the first ReLU (:98)."""
+    b, t, _ = feats.shape
+    x = F.linear(feats, p["input_proj.weight"], p["input_proj.bias"]).permute(0, 2, 1)      # (B,D,T)
+    i = 0
+    while f"f_movie.blocks.{i}.gn1.weight" in p:
+        q = f"f_movie.blocks.{i}"
+        r = x
+        h = F.relu(F.group_norm(x, 32, p[q + ".gn1.weight"], p[q + ".gn1.bias"], eps=1e-5))
+        h = _causal_conv1d(h, p[q + ".conv1.conv.weight"], p[q + ".conv1.conv.bias"])
+        if masks is not None:
+            m = masks[q].view(b, t, -1).permute(0, 2, 1).to(h.dtype)
+            h = h * m / keep
+        h = F.relu(F.group_norm(h, 32, p[q + ".gn2.weight"], p[q + ".gn2.bias"], eps=1e-5))
+        x = _causal_conv1d(h, p[q + ".conv2.conv.weight"], p[q + ".conv2.conv.bias"]) + r
+        i += 1
+    phi = x.permute(0, 2, 1)
+    y = p["f_3D.y0"].to(phi.dtype).view(1, 1, -1).expand(b, t, -1).contiguous()
+    for it in range(3):
+        h = F.relu(F.linear(torch.cat([phi, y], dim=-1), p["f_3D.mlp.0.weight"], p["f_3D.mlp.0.bias"]))
+        if masks is not None:
+            h = h * masks[f"f_3D.{it}"].view(b, t, -1).to(h.dtype) / keep
+        h = F.relu(F.linear(h, p["f_3D.mlp.3.weight"], p["f_3D.mlp.3.bias"]))
+        y = y + F.linear(h, p["f_3D.mlp.5.weight"], p["f_3D.mlp.5.bias"])
+    return y.view(b, t, -1, 3)
+
+
+def train_steps_reference(sd: Dict[str, torch.Tensor], batches, masks_per_step=None, lr: float = 1e-4, weight_decay: float = 1e-2,
+                          dtype=torch.float32):
+    """Run len(batches) phase-1 steps (l3d loss :161, AdamW :389; no loss scaling on the CPU, as the reference's own CPU path).
+    batches: [(feats (B,T,2048), joints3d (B,T,17,3))].  Returns (losses, mpjpes, grads of the FIRST step, final state dict)."""
+    p = {k: v.detach().clone().to(dtype) for k, v in sd.items()}
+    trainable = [k for k in p if k.startswith(TRAINABLE_PREFIXES)]
+    for k in trainable:
+        p[k].requires_grad_(True)
+    opt = torch.optim.AdamW([p[k] for k in trainable], lr=lr, weight_decay=weight_decay)
+    losses, mpjpes, first_grads = [], [], None
+    for s, (feats, gt) in enumerate(batches):
+        opt.zero_grad(set_to_none=True)
+        pred = _forward_train(p, feats.to(dtype), masks_per_step[s] if masks_per_step is not None else None)
+        loss = (pred - gt.to(dtype)).pow(2).mean()
+        loss.backward()
+        if first_grads is None:
+            first_grads = {k: p[k].grad.detach().clone() for k in trainable}
+        opt.step()
+        losses.append(float(loss.detach()))
+        mpjpes.append(float(torch.norm(pred.detach() - gt.to(dtype), dim=-1).mean()))
+    return losses, mpjpes, first_grads, {k: v.detach().clone() for k, v in p.items()}

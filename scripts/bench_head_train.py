@@ -1,0 +1,66 @@
+"""Lifting-head phase-1 training step on one MI355X at train.py's configuration (PHD(1024, 17, 2), batch 32 x 40 frames, fp16,
+AdamW + GradScaler): steps/s, clips/s and the GEMM TFLOP/s of the step; eval forward beside it.  BASELINE configs[3], single GPU.
+    python scripts/bench_head_train.py [--batch 32] [--steps 50]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seq-len", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="fp16")
+    a = ap.parse_args()
+    from implementation_phd_lab_vision_amd import train
+    from implementation_phd_lab_vision_amd.model import expected_keys
+    dev = "cuda:0"
+    d, nb = 1024, 2
+    g = torch.Generator().manual_seed(0)
+    sd = {k: torch.randn(*s, generator=g) * (0.02 if len(s) > 1 else 0.05) for k, s in expected_keys(d, 17, nb).items()}
+    for k in sd:
+        if ".gn" in k and k.endswith("weight"):
+            sd[k] = sd[k] + 1.0
+    sd["f_3D.y0"] = torch.zeros(51)
+    m = train.TrainableHead(d, 17, nb, precision=a.precision)
+    m.load_state_dict(sd); m.to(dev).train()
+    optim, scaler = train.AdamW(m, lr=1e-4), train.GradScaler(init_scale=1024.0)
+    feats = torch.randn(a.batch, a.seq_len, 2048, generator=g).abs().to(dev)
+    gt = (torch.randn(a.batch, a.seq_len, 17, 3, generator=g) * 0.5).to(dev)
+    rows = a.batch * a.seq_len
+    fwd = 2 * rows * (2048 * d + nb * 2 * 3 * d * d + 3 * ((d + 51) * 1024 + 1024 * 1024 + 1024 * 51))
+    bwd = 2 * fwd - 2 * rows * 2048 * d          # dX and dW for every product except input_proj's dX
+    for _ in range(a.warmup):
+        m.train_step(feats, gt, optim, scaler)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, mpjpe, skipped = m.train_step(feats, gt, optim, scaler)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    m.eval()
+    for _ in range(a.warmup):
+        m(feats, predict_future=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        m(feats, predict_future=False)
+    torch.cuda.synchronize()
+    de = (time.perf_counter() - t0) / a.steps
+    print(json.dumps({"workload": f"PHD(1024,17,2) phase-1 train step, batch {a.batch} x {a.seq_len}, {a.precision}, AdamW + GradScaler, dropout on",
+                      "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt, "clips_per_s": a.batch / dt, "gemm_tflops": (fwd + bwd) / dt / 1e12,
+                      "gemm_flop_per_step": fwd + bwd, "last_loss": loss, "eval_forward_ms": de * 1e3,
+                      "eval_forward_clips_per_s": a.batch / de, "trainable_params": int(m.flat_master.numel())}))
+
+
+if __name__ == "__main__":
+    main()
