@@ -1545,15 +1545,25 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(unsigned short* __restric
         dy[i] = ld_e<ET>(act + i) > 0.f ? st_e<ET>(ld_e<ET>(dy + i) * scale) : (unsigned short)0;
 }
 
-// out (cols) fp32 [+]= scale * sum over rows of x (rows, ld)[:, :cols]: bias gradients.  One thread per column, rows in order.
+// out (cols) fp32 [+]= scale * sum over rows of x (rows, ld)[:, :cols]: bias gradients.  A workgroup owns 64 columns; its 16 row
+// groups each sum rows g, g+16, ... in order, and the 16 partials are added in a fixed order (deterministic, no atomics).
 template <int ET>
-__global__ __launch_bounds__(64) void colsum_kernel(const unsigned short* __restrict__ x, long long rows, int cols, int ld,
-                                                    float scale, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= cols) return;
+__global__ __launch_bounds__(1024) void colsum_kernel(const unsigned short* __restrict__ x, long long rows, int cols, int ld,
+                                                      float scale, float* __restrict__ out, int accumulate) {
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (long long r = 0; r < rows; ++r) s += ld_e<ET>(x + r * ld + c);
-    out[c] = (accumulate ? out[c] : 0.f) + s * scale;
+    if (c < cols)
+        for (long long r = grp; r < rows; r += 16) s += ld_e<ET>(x + r * ld + c);
+    part[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += part[g][lane];
+        out[c] = (accumulate ? out[c] : 0.f) + t * scale;
+    }
 }
 __global__ __launch_bounds__(64) void colsum_f32_kernel(const float* __restrict__ x, long long rows, int cols, float scale,
                                                         float* __restrict__ out, int accumulate) {

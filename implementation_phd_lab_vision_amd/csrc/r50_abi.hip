@@ -1299,7 +1299,7 @@ int r50_op_relu_bwd(void* dy, const void* act, float scale, int64_t n, int et, v
 
 int r50_op_colsum(const void* x, int64_t rows, int cols, int ld, float scale, float* out, int accumulate, int et, void* stream) {
     if (!x || !out || rows < 1 || cols < 1 || ld < cols || (et != 0 && et != 1)) return fail(nullptr, R50_ERR_INVALID, "r50_op_colsum: invalid arguments");
-    R50_ET_LAUNCH(colsum_kernel, dim3((cols + 63) / 64), dim3(64), stream, (const unsigned short*)x, (long long)rows, cols, ld, scale, out, accumulate);
+    R50_ET_LAUNCH(colsum_kernel, dim3((cols + 63) / 64), dim3(1024), stream, (const unsigned short*)x, (long long)rows, cols, ld, scale, out, accumulate);
     return ew_done("r50_op_colsum");
 }
 

@@ -131,6 +131,14 @@ class TrainableHead(PHDFor3DJoints):
         super().__init__(latent_dim, joints_num, number_blocks, precision)
         self.flat_master: Optional[torch.Tensor] = None
         self._layout: List[Tuple[str, int, Tuple[int, ...]]] = []
+        self._use_graphs = False
+        self._graphs: Dict[tuple, tuple] = {}
+
+    def enable_graphs(self, on: bool = True) -> "TrainableHead":
+        """Replay forward + loss + backward (~250 short launches) as one captured HIP graph per (B, T, loss scale, mode): the step
+        is launch-bound otherwise.  The optimizer part stays outside (its bias corrections are per-step host scalars)."""
+        self._use_graphs = bool(on)
+        return self
 
     def train(self, mode: bool = True):
         self.training = bool(mode)
@@ -391,12 +399,43 @@ class TrainableHead(PHDFor3DJoints):
                                "r50_op_check_overflow16")
         return y.view(b, t, self.joints_num, 3), loss2
 
+    def _forward_backward_graphed(self, feats: torch.Tensor, joints3d: torch.Tensor, loss_scale: float):
+        b, t, _ = feats.shape
+        key = (b, t, float(loss_scale), self.training)
+        if key not in self._graphs:
+            if len(self._graphs) >= 8:                      # loss scales come and go; keep the cache bounded
+                self._graphs.pop(next(iter(self._graphs)))
+            s_feats = torch.empty((b, t, 2048), dtype=torch.float32, device=self._device)
+            s_gt = torch.empty((b, t, self.joints_num, 3), dtype=torch.float32, device=self._device)
+            s_feats.copy_(feats); s_gt.copy_(joints3d)
+            eager_arena, self._arena = self._arena, _Arena(self._device, self._dtype)
+            try:
+                side = torch.cuda.Stream(self._device)
+                side.wait_stream(torch.cuda.current_stream(self._device))
+                with torch.cuda.stream(side):              # warm-up off the default stream: sizes the arena, loads every kernel
+                    for _ in range(2):
+                        self.forward_backward(s_feats, s_gt, loss_scale)
+                torch.cuda.current_stream(self._device).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    pred, loss2 = self.forward_backward(s_feats, s_gt, loss_scale)
+                self._graphs[key] = (graph, s_feats, s_gt, pred, loss2, self._arena)
+            finally:
+                self._arena = eager_arena
+        graph, s_feats, s_gt, pred, loss2, _ = self._graphs[key]
+        s_feats.copy_(feats); s_gt.copy_(joints3d)
+        graph.replay()
+        return pred, loss2
+
     def train_step(self, feats: torch.Tensor, joints3d: torch.Tensor, optim: AdamW, scaler: Optional[GradScaler] = None,
                    masks: Optional[Dict[str, torch.Tensor]] = None, group=None) -> Tuple[float, float, bool]:
         """src/train.py:137-176 for one batch: forward + l3d, scaled backward, inf check, AdamW, scale update.
         Returns (loss, mpjpe, skipped)."""
         scale = scaler.get_scale() if scaler is not None else 1.0
-        _, loss2 = self.forward_backward(feats, joints3d, scale, masks)
+        if self._use_graphs and masks is None:
+            _, loss2 = self._forward_backward_graphed(feats, joints3d, scale)
+        else:
+            _, loss2 = self.forward_backward(feats, joints3d, scale, masks)
         lib = _lib.load_library()
         with torch.cuda.device(self._device):
             all_reduce_gradients(self.flat_grad, group)

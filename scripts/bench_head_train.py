@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="fp16")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured HIP graph per step")
     a = ap.parse_args()
     from implementation_phd_lab_vision_amd import train
     from implementation_phd_lab_vision_amd.model import expected_keys
@@ -33,6 +34,7 @@ def main():
     sd["f_3D.y0"] = torch.zeros(51)
     m = train.TrainableHead(d, 17, nb, precision=a.precision)
     m.load_state_dict(sd); m.to(dev).train()
+    m.enable_graphs(not a.no_graph)
     optim, scaler = train.AdamW(m, lr=1e-4), train.GradScaler(init_scale=1024.0)
     feats = torch.randn(a.batch, a.seq_len, 2048, generator=g).abs().to(dev)
     gt = (torch.randn(a.batch, a.seq_len, 17, 3, generator=g) * 0.5).to(dev)
@@ -59,7 +61,7 @@ def main():
     print(json.dumps({"workload": f"PHD(1024,17,2) phase-1 train step, batch {a.batch} x {a.seq_len}, {a.precision}, AdamW + GradScaler, dropout on",
                       "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt, "clips_per_s": a.batch / dt, "gemm_tflops": (fwd + bwd) / dt / 1e12,
                       "gemm_flop_per_step": fwd + bwd, "last_loss": loss, "eval_forward_ms": de * 1e3,
-                      "eval_forward_clips_per_s": a.batch / de, "trainable_params": int(m.flat_master.numel())}))
+                      "eval_forward_clips_per_s": a.batch / de, "trainable_params": int(m.flat_master.numel()), "hip_graph": not a.no_graph}))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,36 @@
+"""One rank of the CPU rehearsal of the data-parallel training step (gloo, world_size 2): each rank holds half of the batch,
+computes the oracle's gradients on it, flattens them in a fixed key order and averages the flat buffer with
+``train.all_reduce_gradients`` (the one collective of the step; RCCL on GPUs).  Rank 0 saves the result."""
+import os
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from implementation_phd_lab_vision_amd.train import all_reduce_gradients  # noqa: E402
+from oracle import lifting_oracle as lo  # noqa: E402
+
+
+def main():
+    out = sys.argv[1]
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sd = lo.synthetic_head_state_dict(64, 2, 5)
+    g = torch.Generator().manual_seed(55)
+    feats, gt = torch.randn(4, 6, 2048, generator=g).abs(), torch.randn(4, 6, 17, 3, generator=g)
+    per = feats.shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)
+    _, _, grads, _ = lo.train_steps_reference(sd, [(feats[sl], gt[sl])], dtype=torch.float64)
+    flat = torch.cat([grads[k].reshape(-1) for k in sorted(grads)])
+    all_reduce_gradients(flat)
+    if rank == 0:
+        torch.save({"flat": flat, "keys": sorted(grads)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,3 +61,32 @@ def test_sharding_helpers():
     assert D.rank_clip_indices(0, bs, 0, world) == [] and D.n_rounds(0, bs, world) == 0
     # more ranks than batches: the extra ranks simply idle
     assert D.rank_clip_indices(3, 4, 1, 8) == [] and D.n_rounds(3, 4, 8) == 1
+
+
+def test_data_parallel_gradient_average_equals_full_batch(tmp_path):
+    """Training step, N > 1: the mean of the per-rank gradients (one all-reduce of the flat buffer) is the full-batch gradient."""
+    import torch
+    from oracle import lifting_oracle as lo
+    port, world, out = _free_port(), 2, tmp_path / "flat.pt"
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dist_train_worker.py"), str(out)], env=env, cwd=str(ROOT),
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for rank, p in enumerate(procs):
+        try:
+            o, _ = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, f"rank {rank} failed:\n{o.decode(errors='replace')[-3000:]}"
+    got = torch.load(out, weights_only=True)
+    sd = lo.synthetic_head_state_dict(64, 2, 5)
+    g = torch.Generator().manual_seed(55)
+    feats, gt = torch.randn(4, 6, 2048, generator=g).abs(), torch.randn(4, 6, 17, 3, generator=g)
+    _, _, grads, _ = lo.train_steps_reference(sd, [(feats, gt)], dtype=torch.float64)
+    assert got["keys"] == sorted(grads)
+    want = torch.cat([grads[k].reshape(-1) for k in sorted(grads)])
+    torch.testing.assert_close(got["flat"], want, rtol=1e-9, atol=1e-12)
