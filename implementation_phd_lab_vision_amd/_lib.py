@@ -74,6 +74,8 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "r50_op_crop_resize_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "r50_op_color_jitter_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_float, C.c_float, C.c_float, C.c_float,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "r50_op_cast_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "r50_op_concat_pad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "r50_op_add_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p]),

@@ -1503,6 +1503,101 @@ __global__ __launch_bounds__(256) void gn_relu_causal3_kernel(const unsigned sho
 }
 
 // ------------------------------------------------------------------------------------------------
+// ColorJitter variant (`_aug_color_jitter`, src/dataset.py:188-197 = torchvision.transforms.v2.ColorJitter
+// on the float clip in [0,1]): brightness / contrast / saturation / hue in a sampled order, one set of factors per clip.
+// Planar fp32 (T,3,H*W) work buffer; every op follows torchvision's v2 float kernels operation by operation
+// (transforms/v2/functional/_color.py; restated in oracle/colorjitter_oracle.py).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cj_from_u8_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (float)src[i] / 255.0f;
+}
+
+// r.mul(0.2989).add_(g, alpha=0.587).add_(b, alpha=0.114): ATen's add-with-alpha is a fused multiply-add on the CPU's vector path
+__device__ __forceinline__ float cj_gray(float r, float g, float b) { return fmaf(b, 0.114f, fmaf(g, 0.587f, r * 0.2989f)); }
+__device__ __forceinline__ float cj_clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+// _blend: image1.mul(ratio).add_(image2, alpha=1 - ratio).clamp_(0, 1)
+__device__ __forceinline__ float cj_blend(float a, float b, float ratio) { return cj_clamp01(fmaf(b, 1.0f - ratio, a * ratio)); }
+
+// mean[t] = mean over the frame of the grayscale image (adjust_contrast's blend target).  One workgroup per frame; per-thread sums
+// in pixel order, then a fixed-order tree.
+__global__ __launch_bounds__(1024) void cj_gray_mean_kernel(const float* __restrict__ img, int hw, float* __restrict__ mean) {
+    __shared__ float red[1024];
+    const float* f = img + (size_t)blockIdx.x * 3 * hw;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 1024) s += cj_gray(f[i], f[hw + i], f[2 * hw + i]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mean[blockIdx.x] = red[0] / (float)hw;
+}
+
+// op: 0 brightness, 1 contrast (mean per frame), 2 saturation, 3 hue; in place on (T,3,hw) fp32
+__global__ __launch_bounds__(256) void cj_apply_kernel(float* __restrict__ img, int t, int hw, int op, float factor,
+                                                       const float* __restrict__ mean) {
+    const long long total = (long long)t * hw;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long fr = i / hw;
+        float* p = img + fr * 3 * hw + (i - fr * hw);
+        float r = p[0], g = p[hw], b = p[2 * hw];
+        if (op == 0) {
+            r = cj_clamp01(r * factor); g = cj_clamp01(g * factor); b = cj_clamp01(b * factor);
+        } else if (op == 1) {
+            const float m = mean[fr];
+            r = cj_blend(r, m, factor); g = cj_blend(g, m, factor); b = cj_blend(b, m, factor);
+        } else if (op == 2) {
+            const float y = cj_gray(r, g, b);
+            r = cj_blend(r, y, factor); g = cj_blend(g, y, factor); b = cj_blend(b, y, factor);
+        } else {
+            // _rgb_to_hsv
+            const float maxc = fmaxf(fmaxf(r, g), b), minc = fminf(fminf(r, g), b);
+            const bool eqc = maxc == minc;
+            const float cr = maxc - minc;
+            const float sat = cr / (eqc ? 1.0f : maxc);
+            const float div = eqc ? 1.0f : cr;
+            const float rc = (maxc - r) / div, gc = (maxc - g) / div, bc = (maxc - b) / div;
+            const bool neq_r = maxc != r, eq_g = maxc == g;
+            const float hg = (eq_g && neq_r) ? (rc + 2.0f) - bc : 0.f;
+            const float hr = !neq_r ? bc - gc : 0.f;
+            const float hb = (neq_r && !eq_g) ? (gc + 4.0f) - rc : 0.f;
+            float h = (hr + hg) + hb;
+            h = fmodf(h * (1.0f / 6.0f) + 1.0f, 1.0f);
+            // h.add_(hue_factor).remainder_(1.0)
+            h = h + factor;
+            h = h - floorf(h);                         // remainder by 1.0 (sign of the divisor)
+            if (h >= 1.0f) h = 0.f;                    // -tiny + 1 rounds to 1: remainder's result stays below the divisor
+            // _hsv_to_rgb
+            const float h6 = h * 6.0f;
+            const float fl = floorf(h6);
+            const float f = h6 - fl;
+            int k = (int)fl % 6; if (k < 0) k += 6;
+            const float sxf = sat * f, oms = 1.0f - sat;
+            const float q = cj_clamp01((1.0f - sxf) * maxc);
+            const float tt = cj_clamp01((sxf + oms) * maxc);
+            const float pp = cj_clamp01(oms * maxc);
+            const float v = maxc;
+            r = k == 0 ? v : k == 1 ? q : k == 2 ? pp : k == 3 ? pp : k == 4 ? tt : v;
+            g = k == 0 ? tt : k == 1 ? v : k == 2 ? v : k == 3 ? q : k == 4 ? pp : pp;
+            b = k == 0 ? pp : k == 1 ? pp : k == 2 ? tt : k == 3 ? v : k == 4 ? v : q;
+        }
+        p[0] = r; p[hw] = g; p[2 * hw] = b;
+    }
+}
+
+// frame_tf = Normalize(mean, std) (src/dataset.py:242-245) in place: (x - mean[c]) / std[c]
+__global__ __launch_bounds__(256) void cj_normalize_kernel(float* __restrict__ img, long long planes, int hw, float m0, float m1, float m2,
+                                                           float s0, float s1, float s2) {
+    const long long total = planes * hw;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)((i / hw) % 3);
+        const float m = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        img[i] = (img[i] - m) / sd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Lifting head, backward + optimizer (the training step of src/train.py:137-176).  Every matrix product of
 // the backward pass (dX = dY W, dW = dY^T X) is again an igemm launch (operands transposed by transpose16_kernel so that
 // both are K-contiguous); what follows are the byte-moving pieces around them.

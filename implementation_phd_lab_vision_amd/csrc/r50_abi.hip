@@ -1266,6 +1266,35 @@ int r50_op_gn_relu_causal3(const void* x, int b, int t, int c, int groups, const
     return e == hipSuccess ? R50_OK : fail(nullptr, R50_ERR_HIP, std::string("r50_op_gn_relu_causal3: ") + hipGetErrorString(e));
 }
 
+// ---- ColorJitter variant (kernels.h: cj_*_kernel) ----
+int r50_op_color_jitter_u8(const void* frames_u8, int t, int hw, const int* order4, float brightness, float contrast, float saturation,
+                           float hue, int normalize, float* out_f32, float* scratch_means, void* stream) {
+    if (!frames_u8 || !order4 || !out_f32 || !scratch_means || t < 1 || hw < 1)
+        return fail(nullptr, R50_ERR_INVALID, "r50_op_color_jitter_u8: invalid arguments");
+    int seen = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (order4[i] < 0 || order4[i] > 3) return fail(nullptr, R50_ERR_INVALID, "r50_op_color_jitter_u8: order entries must be 0..3");
+        seen |= 1 << order4[i];
+    }
+    if (seen != 15) return fail(nullptr, R50_ERR_INVALID, "r50_op_color_jitter_u8: order must be a permutation of 0..3");
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = (long long)t * 3 * hw;
+    const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(cj_from_u8_kernel, dim3(grid), dim3(256), 0, s, (const unsigned char*)frames_u8, out_f32, n);
+    const float factor[4] = {brightness, contrast, saturation, hue};
+    for (int i = 0; i < 4; ++i) {
+        const int op = order4[i];
+        if (op == 3 && hue == 0.0f) continue;                       // adjust_hue returns its input for a zero factor
+        if (op == 1) hipLaunchKernelGGL(cj_gray_mean_kernel, dim3(t), dim3(1024), 0, s, out_f32, hw, scratch_means);
+        hipLaunchKernelGGL(cj_apply_kernel, dim3(grid), dim3(256), 0, s, out_f32, t, hw, op, factor[op], scratch_means);
+    }
+    if (normalize)
+        hipLaunchKernelGGL(cj_normalize_kernel, dim3(grid), dim3(256), 0, s, out_f32, (long long)t * 3, hw, 0.485f, 0.456f, 0.406f, 0.229f,
+                           0.224f, 0.225f);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? R50_OK : fail(nullptr, R50_ERR_HIP, std::string("r50_op_color_jitter_u8: ") + hipGetErrorString(e));
+}
+
 // ---- lifting head, backward + optimizer (kernels.h, "Lifting head, backward + optimizer") ----
 static unsigned ew_grid(long long n) { return (unsigned)std::min<long long>(std::max<long long>((n + 255) / 256, 1), 256 * 32); }
 static int ew_done(const char* what) {

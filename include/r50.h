@@ -179,6 +179,15 @@ int r50_op_bneck_tail(const void* y2_bf16, int64_t m, int cmid, const void* w3_b
 int r50_op_crop_resize_u8(const void* frames_thwc_u8, int t, int h, int w, int top, int left, int hh, int ww,
                           void* out_tchw_u8, int out_size, int mode, int flags, void* stream);
 
+/* ColorJitter augmentation variant: `_aug_color_jitter` (src/dataset.py:188-197) = torchvision.transforms.v2
+ * ColorJitter(brightness=0.3, contrast=0.3, saturation=0.2, hue=0.05) on the float clip in [0,1], followed (normalize != 0) by
+ * `frame_tf` = Normalize(ImageNet mean, std) (:242-245).  frames_u8: (t,3,hw) uint8 resized crops on the device (the output of
+ * r50_op_crop_resize_u8); order4: the sampled permutation of {0 brightness, 1 contrast, 2 saturation, 3 hue} (HOST pointer); the
+ * four factors as sampled (host code: frames.sample_color_jitter_params); out_f32: (t,3,hw) fp32, what r50_forward takes;
+ * scratch_means: t floats of device memory (per-frame grayscale mean of adjust_contrast).  Asynchronous on `stream`. */
+int r50_op_color_jitter_u8(const void* frames_u8, int t, int hw, const int* order4_host, float brightness, float contrast,
+                           float saturation, float hue, int normalize, float* out_f32, float* scratch_means, void* stream);
+
 /* Lifting head, forward (first step): the non-GEMM pieces of `PHDFor3DJoints.forward` (src/model.py:146-178);
  * its Linear layers and causal conv1d's run on r50_op_conv2d / r50_op_conv2d_f16 as 1x1 convolutions over the b*t rows.
  * et: 0 = bf16, 1 = fp16.  All device pointers.
