@@ -2194,6 +2194,169 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const TIN* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused stem, strip version: the same arithmetic as stem_fused_kernel (bit-identical output), but a workgroup walks G
+// consecutive pooled-row pairs of ONE image (G = 28: the whole image) and keeps what consecutive pairs share: the 7 input rows
+// and the conv row that the next pair needs again stay in LDS (rings of 16 input-row slots and 6 conv-row slots).  Per pair
+// that is 8 new input rows instead of 15 and 4 new conv rows instead of 5 -- and 4 rows x 2 channel halves are exactly 8 waves,
+// two per SIMD, where 5 row-waves left one SIMD with twice the MFMA work of the others.
+// LDS: weights 28,672 B | input ring 16 x 1,856 B | conv ring 6 x 112 x 128 B | u8 table 3,072 B = 147,456 B.
+// ------------------------------------------------------------------------------------------------
+constexpr int SF2_IN_SLOTS = 16;
+constexpr int SF2_OUT_SLOTS = 6;
+constexpr int SF2_IN_BYTES = SF2_IN_SLOTS * STEM_ROW_BYTES;
+constexpr int SF2_OUT_BYTES = SF2_OUT_SLOTS * 112 * 128;
+constexpr int SF2_LDS_BYTES = STEM_W_BYTES + SF2_IN_BYTES + SF2_OUT_BYTES + SF_TAB_BYTES;
+constexpr int SF2_PACK_ROWS = 4;                      // rows per packing thread and round: threads [0,232) rows 0-3, [232,464) rows 4-7
+
+template <int ET, typename TIN>
+__global__ __launch_bounds__(SF_THREADS) void stem_fused2_kernel(const TIN* __restrict__ x, const char* __restrict__ wpk,
+                                                                 const float* __restrict__ bias, __bf16* __restrict__ y,
+                                                                 int n_strips, int G, const float* __restrict__ u8_table) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w = smem;
+    char* s_in = smem + STEM_W_BYTES;
+    char* s_out = smem + STEM_W_BYTES + SF2_IN_BYTES;
+    float* s_tab = reinterpret_cast<float*>(smem + STEM_W_BYTES + SF2_IN_BYTES + SF2_OUT_BYTES);
+    constexpr bool U8 = (sizeof(TIN) == 1);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rr = wave >> 1, ch = wave & 1;           // conv row of the round, channel half (couts 32*ch .. 32*ch+31)
+
+    for (int c = tid; c < STEM_W_BYTES / 16; c += SF_THREADS)
+        *reinterpret_cast<u32x4*>(s_w + c * 16) = *reinterpret_cast<const u32x4*>(wpk + c * 16);
+    if constexpr (U8) {
+        for (int c = tid; c < 3 * 256; c += SF_THREADS) s_tab[c] = u8_table[c];
+    }
+
+    const int p_half = tid >= STEM_WP ? 1 : 0;
+    const int p_wp = tid - p_half * STEM_WP;
+    const bool p_active = tid < 2 * STEM_WP;
+    const bool p_col_ok = p_active && (unsigned)(p_wp - 4) < 224u;
+    float pc[SF2_PACK_ROWS][3];
+    auto load_rows = [&](int n, int first_row) {       // input rows first_row .. first_row + 7 of image n -> registers
+        const int in0 = first_row + p_half * SF2_PACK_ROWS;
+        const TIN* base = x + (size_t)n * 3 * 224 * 224 + (p_col_ok ? p_wp - 4 : 0);
+#pragma unroll
+        for (int r = 0; r < SF2_PACK_ROWS; ++r) {
+            const int hi = in0 + r;
+            const bool ok = p_col_ok && (unsigned)hi < 224u;
+            const TIN* p = base + (ok ? hi * 224 : 0);
+            if constexpr (U8) {
+                pc[r][0] = ok ? (float)p[0] : -1.f;
+                pc[r][1] = ok ? (float)p[224 * 224] : -1.f;
+                pc[r][2] = ok ? (float)p[2 * 224 * 224] : -1.f;
+            } else {
+                pc[r][0] = ok ? frame_value(p, 0) : 0.f;
+                pc[r][1] = ok ? frame_value(p + 224 * 224, 1) : 0.f;
+                pc[r][2] = ok ? frame_value(p + 2 * 224 * 224, 2) : 0.f;
+            }
+        }
+    };
+    auto sample = [&](float v, int c) -> float {
+        if constexpr (U8) return v < 0.f ? 0.f : s_tab[c * 256 + (int)v];
+        else return v;
+    };
+    auto store_rows = [&](int first_row) {             // registers -> ring slots (row + 32) & 15, bf16 [wp][4]
+        if (p_active) {
+#pragma unroll
+            for (int r = 0; r < SF2_PACK_ROWS; ++r) {
+                const int slot = (first_row + p_half * SF2_PACK_ROWS + r + 32) & (SF2_IN_SLOTS - 1);
+                *reinterpret_cast<u32x2*>(s_in + (slot * STEM_WP + p_wp) * 8) =
+                    (u32x2){pack2_e<ET>(sample(pc[r][0], 0), sample(pc[r][1], 1)), pack2_e<ET>(sample(pc[r][2], 2), 0.f)};
+            }
+        }
+    };
+    // conv row c (0 <= c < 112) of this wave's channel half: input rows 2c-3 .. 2c+3 from the ring -> conv ring slot c % 6
+    auto conv_row = [&](int c) {
+        f32x4 acc[2][7];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int w_frag = fr * 64 + fq * 16;
+        const int x_lane = fr * 16 + fq * 16;
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            const int slot = __builtin_amdgcn_readfirstlane((2 * c - 3 + kh + 32) & (SF2_IN_SLOTS - 1));
+            bf16x8 wf[2], xf[7];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(s_w + kh * 4096 + (2 * ch + m) * 1024 + w_frag);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(s_in + slot * STEM_ROW_BYTES + x_lane + j * 256);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc[m][j] = mfma_e<ET>(wf[m], xf[j], acc[m][j]);
+        }
+        const int oslot = __builtin_amdgcn_readfirstlane(c % SF2_OUT_SLOTS);
+        const int cout = 32 * ch + 8 * fq;
+        const f32x4 b_lo = *reinterpret_cast<const f32x4*>(bias + cout);
+        const f32x4 b_hi = *reinterpret_cast<const f32x4*>(bias + cout + 4);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int wo = 16 * j + fr;
+            u32x4 out;
+            out[0] = relu_bf16x2(pack2_e<ET>(acc[0][j][0] + b_lo[0], acc[0][j][1] + b_lo[1]));
+            out[1] = relu_bf16x2(pack2_e<ET>(acc[0][j][2] + b_lo[2], acc[0][j][3] + b_lo[3]));
+            out[2] = relu_bf16x2(pack2_e<ET>(acc[1][j][0] + b_hi[0], acc[1][j][1] + b_hi[1]));
+            out[3] = relu_bf16x2(pack2_e<ET>(acc[1][j][2] + b_hi[2], acc[1][j][3] + b_hi[3]));
+            *reinterpret_cast<u32x4*>(s_out + (oslot * 112 + wo) * 128 + (((4 * ch + fq) ^ (wo & 7)) << 4)) = out;
+        }
+    };
+
+    const int spi = 28 / G;                            // strips per image
+    for (int strip = blockIdx.x; strip < n_strips; strip += gridDim.x) {
+        const int n = strip / spi;
+        const int t0 = (strip - n * spi) * G;          // first pooled-row pair of the strip
+        __syncthreads();                               // the previous strip's readers of both rings are done (and s_w is staged)
+        load_rows(n, 8 * t0 - 6);                      // rows 4 r0 - 6 .. 4 r0 + 1 (r0 = 2 t0): what a running strip would already hold
+        store_rows(8 * t0 - 6);
+        load_rows(n, 8 * t0 + 2);
+        for (int ti = 0; ti < G; ++ti) {
+            const int r0 = 2 * (t0 + ti);              // first pooled row of the pair
+            store_rows(4 * r0 + 2);                    // the pair's 8 new input rows 4 r0 + 2 .. 4 r0 + 9
+            __syncthreads();                           // input ring ready; the previous pair's pooling is finished
+            if (ti + 1 < G) load_rows(n, 4 * r0 + 10);
+            if (ti == 0 && r0 > 0 && rr == 3) conv_row(2 * r0 - 1);       // a strip that starts inside the image: the shared conv row
+            conv_row(2 * r0 + rr);                     // the pair's 4 new conv rows 2 r0 .. 2 r0 + 3
+            __syncthreads();                           // conv ring complete
+            if (tid < 56 * 8) {
+                const int g = tid & 7, q = tid >> 3;
+                u32x4 hrow[SF_CONV_ROWS];
+#pragma unroll
+                for (int lrow = 0; lrow < SF_CONV_ROWS; ++lrow) {
+                    u32x4 h = (u32x4){0u, 0u, 0u, 0u};
+                    const int c = 2 * r0 - 1 + lrow;
+                    if (c >= 0) {                      // c <= 111 always
+                        const int oslot = c % SF2_OUT_SLOTS;
+#pragma unroll
+                        for (int dw = 0; dw < 3; ++dw) {
+                            const int wo = 2 * q - 1 + dw;
+                            if (wo >= 0) {
+                                const u32x4 v = *reinterpret_cast<const u32x4*>(s_out + (oslot * 112 + wo) * 128 + ((g ^ (wo & 7)) << 4));
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) h[e] = max_bf16x2_nonneg(h[e], v[e]);
+                            }
+                        }
+                    }
+                    hrow[lrow] = h;
+                }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    u32x4 out;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        out[e] = max_bf16x2_nonneg(max_bf16x2_nonneg(hrow[2 * pr][e], hrow[2 * pr + 1][e]), hrow[2 * pr + 2][e]);
+                    *reinterpret_cast<u32x4*>(y + (((size_t)n * 56 + r0 + pr) * 56 + q) * 64 + g * 8) = out;
+                }
+            }
+        }
+    }
+}
+
 // ================================================================================================
 // Split-precision ("fp32x") variants of the non-GEMM kernels.  In this mode every activation travels
 // as a pair of bf16 tensors (head, tail) with head + tail ~ the fp32 value (16 mantissa bits), stored

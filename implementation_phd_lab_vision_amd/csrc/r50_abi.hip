@@ -6,6 +6,7 @@
 #include "../../include/r50.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -584,6 +585,9 @@ hipError_t launch_stem_conv(const void* xp, const void* wpk, const float* bias, 
                        (const char*)xp, (const char*)wpk, bias, (__bf16*)y);
     return hipGetLastError();
 }
+// fused stem variant: 0 = strip version (stem_fused2_kernel) with the strip length chosen from the batch, 1/2/4/7/14/28 = that strip
+// length, -1 = the per-pair version (stem_fused_kernel).  r50_set_option("stem_strip") or R50_STEM_STRIP in the environment (A/B).
+static int g_stem_strip = [] { const char* v = std::getenv("R50_STEM_STRIP"); return v ? std::atoi(v) : 0; }();
 template <typename TIN>
 hipError_t launch_stem_fused(const TIN* x, const void* wpk, const float* bias, void* y, int n, hipStream_t s,
                              const float* u8_table, int et = 0) {
@@ -597,6 +601,22 @@ hipError_t launch_stem_fused(const TIN* x, const void* wpk, const float* bias, v
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
         g_num_cus = prop.multiProcessorCount;
+    }
+    if (g_stem_strip >= 0) {
+        // strip version: a workgroup walks G consecutive pooled-row pairs of one image; G = the longest strip that still gives
+        // the chip ~200 workgroups (28 = the whole image from batch 200 up)
+        int G = 1;
+        if (g_stem_strip > 0) G = g_stem_strip;
+        else
+            for (int cand : {28, 14, 7, 4, 2})
+                if (n * (28 / cand) >= 200) { G = cand; break; }
+        auto kern2 = et == 1 ? stem_fused2_kernel<1, TIN> : stem_fused2_kernel<0, TIN>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, SF2_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        const int strips = n * (28 / G);
+        const int grid2 = strips < g_num_cus ? strips : g_num_cus;
+        hipLaunchKernelGGL(kern2, dim3(grid2), dim3(SF_THREADS), SF2_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, strips, G, u8_table);
+        return hipGetLastError();
     }
     const int tiles = n * 28;
     const int grid = tiles < g_num_cus ? tiles : g_num_cus;       // 128 KB of LDS: one workgroup per CU
@@ -1028,6 +1048,10 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "tile") h->tile_override = (int)value;
     else if (k == "fused_stem") h->fused_stem = value ? 1 : 0;
     else if (k == "fuse_tail") h->fuse_tail = value ? 1 : 0;
+    else if (k == "stem_strip") {          // process-wide (the launcher is shared by the handle and the r50_op_* hooks)
+        if (!(value == -1 || value == 0 || (value > 0 && 28 % value == 0))) return fail(h, R50_ERR_INVALID, "stem_strip must be -1, 0 or a divisor of 28");
+        g_stem_strip = (int)value;
+    }
     else if (k == "overlap_ds") h->overlap_ds = value ? 1 : 0;
     else if (k == "streams") { if (value < 1 || value > 4) return fail(h, R50_ERR_INVALID, "streams must be in [1,4]"); h->n_streams = (int)value; }
     else return fail(h, R50_ERR_INVALID, "r50_set_option: unknown key " + k);
@@ -1043,6 +1067,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "streams") *value = h->n_streams;
     else if (k == "fused_stem") *value = h->fused_stem;
     else if (k == "fuse_tail") *value = h->fuse_tail;
+    else if (k == "stem_strip") *value = g_stem_strip;
     else if (k == "overlap_ds") *value = h->overlap_ds;
     else if (k == "max_batch") *value = h->max_batch;
     else if (k == "workspace_bytes") *value = (int64_t)(5 * h->buf_bytes + (size_t)h->max_batch * STEM_HP * STEM_WP * 8);

@@ -179,6 +179,14 @@ def test_fused_stem_equals_unfused(setup):
     fused = bb.layer(xd, "pool")                       # fused kernel (the 'stem' tap alone forces the unfused path)
     unfused = ops.maxpool_bf16(bb.layer(xd, "stem").contiguous())
     assert torch.equal(fused, unfused)
+    # every strip length of the strip kernel (workgroup = G consecutive pooled-row pairs of an image, shared rows kept in LDS
+    # rings) and the per-pair kernel (-1): all the same bits
+    try:
+        for g in (1, 2, 4, 7, 14, 28, -1):
+            bb.set_option("stem_strip", g)
+            assert torch.equal(bb.layer(xd, "pool"), unfused), g
+    finally:
+        bb.set_option("stem_strip", 0)
     bb.set_option("fused_stem", 0)
     try:
         assert torch.equal(bb.layer(xd, "pool"), unfused)
