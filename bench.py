@@ -95,6 +95,7 @@ def main() -> None:
                          "kernel; video = decoded 1002x1000 uint8 HWC frames + a 500-pixel crop box: crop + bilinear resize on the device too")
     ap.add_argument("--no-fused-stem", action="store_true", help="A/B: run conv1 / maxpool as separate kernels")
     ap.add_argument("--no-fuse-tail", action="store_true", help="A/B: layer1 conv3 and the next conv1 as two igemm launches")
+    ap.add_argument("--no-stem-c1", action="store_true", help="A/B: layer1.0.conv1 as its own igemm launch instead of inside the stem kernel")
     ap.add_argument("--no-overlap-ds", action="store_true", help="A/B: downsample convs on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -132,6 +133,8 @@ def main() -> None:
         bb.set_option("streams", args.streams)
     if args.no_fused_stem:
         bb.set_option("fused_stem", 0)
+    if args.no_stem_c1:
+        bb.set_option("fuse_stem_c1", 0)
     if args.no_fuse_tail:
         bb.set_option("fuse_tail", 0)
     if args.no_overlap_ds:

@@ -2200,24 +2200,32 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const TIN* __res
 // and the conv row that the next pair needs again stay in LDS (rings of 16 input-row slots and 6 conv-row slots).  Per pair
 // that is 8 new input rows instead of 15 and 4 new conv rows instead of 5 -- and 4 rows x 2 channel halves are exactly 8 waves,
 // two per SIMD, where 5 row-waves left one SIMD with twice the MFMA work of the others.
-// LDS: weights 28,672 B | input ring 16 x 1,856 B | conv ring 6 x 112 x 128 B | u8 table 3,072 B = 147,456 B.
+// C1: layer1.0.conv1 (1x1, 64 -> 64, + bias + ReLU) rides along: the pooled pair of rows (112 pixels x 64 channels) is also kept
+// in LDS as the B operand of a 64x64x112 GEMM whose A fragments (the whole weight matrix, 16 registers per lane) live in
+// registers; it runs one pair behind, at the start of the next pair's MFMA phase, so it needs no barrier of its own.  Same
+// accumulation order as the igemm launch it replaces (accumulator = bias, K-steps 0..31, 32..63): bit-identical y1.
+// LDS: weights 28,672 B | input ring 16 x 1,856 B | conv ring 5 x 112 x 128 B | pooled pair 14,336 B (C1) | u8 table 3,072 B = 147,456 B.
 // ------------------------------------------------------------------------------------------------
 constexpr int SF2_IN_SLOTS = 16;
-constexpr int SF2_OUT_SLOTS = 6;
+constexpr int SF2_OUT_SLOTS = 5;                      // 4 new conv rows per pair + the one the previous pair left
 constexpr int SF2_IN_BYTES = SF2_IN_SLOTS * STEM_ROW_BYTES;
 constexpr int SF2_OUT_BYTES = SF2_OUT_SLOTS * 112 * 128;
-constexpr int SF2_LDS_BYTES = STEM_W_BYTES + SF2_IN_BYTES + SF2_OUT_BYTES + SF_TAB_BYTES;
+constexpr int SF2_POOL_BYTES = 112 * 128;
+constexpr int SF2_LDS_BYTES = STEM_W_BYTES + SF2_IN_BYTES + SF2_OUT_BYTES + SF2_POOL_BYTES + SF_TAB_BYTES;
 constexpr int SF2_PACK_ROWS = 4;                      // rows per packing thread and round: threads [0,232) rows 0-3, [232,464) rows 4-7
 
-template <int ET, typename TIN>
+template <int ET, typename TIN, bool C1>
 __global__ __launch_bounds__(SF_THREADS) void stem_fused2_kernel(const TIN* __restrict__ x, const char* __restrict__ wpk,
                                                                  const float* __restrict__ bias, __bf16* __restrict__ y,
-                                                                 int n_strips, int G, const float* __restrict__ u8_table) {
+                                                                 int n_strips, int G, const float* __restrict__ u8_table,
+                                                                 const __bf16* __restrict__ c1_w, const float* __restrict__ c1_bias,
+                                                                 __bf16* __restrict__ y1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_w = smem;
     char* s_in = smem + STEM_W_BYTES;
     char* s_out = smem + STEM_W_BYTES + SF2_IN_BYTES;
-    float* s_tab = reinterpret_cast<float*>(smem + STEM_W_BYTES + SF2_IN_BYTES + SF2_OUT_BYTES);
+    char* s_pool = smem + STEM_W_BYTES + SF2_IN_BYTES + SF2_OUT_BYTES;
+    float* s_tab = reinterpret_cast<float*>(smem + STEM_W_BYTES + SF2_IN_BYTES + SF2_OUT_BYTES + SF2_POOL_BYTES);
     constexpr bool U8 = (sizeof(TIN) == 1);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -2307,6 +2315,43 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused2_kernel(const TIN* __re
         }
     };
 
+    // layer1.0.conv1: this wave's 32 output channels x K = 64 as A fragments.  Accumulator block m, row 4 q + e is channel
+    // 32 ch + 8 q + 4 m + e (the igemm kernels' convention: a lane ends up with 8 consecutive channels of its pixel)
+    bf16x8 a1[2][2];
+    float c1b[2][4];
+    if constexpr (C1) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int chan = 32 * ch + 8 * (fr >> 2) + (fr & 3) + 4 * m;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) a1[m][kk] = *reinterpret_cast<const bf16x8*>(c1_w + chan * 64 + kk * 32 + fq * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c1b[m][e] = c1_bias[32 * ch + 8 * fq + 4 * m + e];
+        }
+    }
+    auto conv1_pair = [&](int n, int r0) {              // y1 rows r0, r0 + 1 of image n from the pooled pair in s_pool
+        if constexpr (C1) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int jb = rr + 4 * half;          // pixel blocks {rr, rr + 4}; 7 blocks in all
+                if (jb < 7) {
+                    const int p = 16 * jb + fr;
+                    f32x4 lo = (f32x4){c1b[0][0], c1b[0][1], c1b[0][2], c1b[0][3]};
+                    f32x4 hi = (f32x4){c1b[1][0], c1b[1][1], c1b[1][2], c1b[1][3]};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(s_pool + p * 128 + (((4 * kk + fq) ^ (p & 7)) << 4));
+                        lo = mfma_e<ET>(a1[0][kk], xb, lo);
+                        hi = mfma_e<ET>(a1[1][kk], xb, hi);
+                    }
+                    u32x4 o = (u32x4){relu_bf16x2(pack2_e<ET>(lo[0], lo[1])), relu_bf16x2(pack2_e<ET>(lo[2], lo[3])),
+                                      relu_bf16x2(pack2_e<ET>(hi[0], hi[1])), relu_bf16x2(pack2_e<ET>(hi[2], hi[3]))};
+                    *reinterpret_cast<u32x4*>(y1 + (((size_t)n * 56 + r0) * 56 + p) * 64 + 32 * ch + 8 * fq) = o;
+                }
+            }
+        }
+    };
+
     const int spi = 28 / G;                            // strips per image
     for (int strip = blockIdx.x; strip < n_strips; strip += gridDim.x) {
         const int n = strip / spi;
@@ -2320,6 +2365,7 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused2_kernel(const TIN* __re
             store_rows(4 * r0 + 2);                    // the pair's 8 new input rows 4 r0 + 2 .. 4 r0 + 9
             __syncthreads();                           // input ring ready; the previous pair's pooling is finished
             if (ti + 1 < G) load_rows(n, 4 * r0 + 10);
+            if (ti > 0) conv1_pair(n, r0 - 2);         // the previous pair's pooled rows are complete in s_pool
             if (ti == 0 && r0 > 0 && rr == 3) conv_row(2 * r0 - 1);       // a strip that starts inside the image: the shared conv row
             conv_row(2 * r0 + rr);                     // the pair's 4 new conv rows 2 r0 .. 2 r0 + 3
             __syncthreads();                           // conv ring complete
@@ -2351,8 +2397,16 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused2_kernel(const TIN* __re
                     for (int e = 0; e < 4; ++e)
                         out[e] = max_bf16x2_nonneg(max_bf16x2_nonneg(hrow[2 * pr][e], hrow[2 * pr + 1][e]), hrow[2 * pr + 2][e]);
                     *reinterpret_cast<u32x4*>(y + (((size_t)n * 56 + r0 + pr) * 56 + q) * 64 + g * 8) = out;
+                    if constexpr (C1) {
+                        const int pp = pr * 56 + q;
+                        *reinterpret_cast<u32x4*>(s_pool + pp * 128 + ((g ^ (pp & 7)) << 4)) = out;
+                    }
                 }
             }
+        }
+        if constexpr (C1) {                            // the strip's last pair
+            __syncthreads();
+            conv1_pair(n, 2 * (t0 + G - 1));
         }
     }
 }

@@ -52,6 +52,7 @@ struct r50_handle {
     hipStream_t ds_stream = nullptr;
     hipEvent_t ev_ds_fork = nullptr, ev_ds_join = nullptr;
     int fused_stem = 1;                 // bf16 mode: conv1+bn1+relu+maxpool in one kernel
+    int fuse_stem_c1 = 1;               // strip stem kernel also computes layer1.0.conv1
     int fuse_tail = 1;                  // bf16 mode, layer1: conv3 + identity + ReLU + the next block's conv1 in one kernel
     int n_streams = 1;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -588,9 +589,12 @@ hipError_t launch_stem_conv(const void* xp, const void* wpk, const float* bias, 
 // fused stem variant: 0 = strip version (stem_fused2_kernel) with the strip length chosen from the batch, 1/2/4/7/14/28 = that strip
 // length, -1 = the per-pair version (stem_fused_kernel).  r50_set_option("stem_strip") or R50_STEM_STRIP in the environment (A/B).
 static int g_stem_strip = [] { const char* v = std::getenv("R50_STEM_STRIP"); return v ? std::atoi(v) : 0; }();
+bool stem_strip_enabled() { return g_stem_strip >= 0; }
+// c1_w / c1_bias / y1 non-null (strip version only): layer1.0.conv1 (+ bias + ReLU) of the pooled output into y1 in the same launch
 template <typename TIN>
 hipError_t launch_stem_fused(const TIN* x, const void* wpk, const float* bias, void* y, int n, hipStream_t s,
-                             const float* u8_table, int et = 0) {
+                             const float* u8_table, int et = 0, const void* c1_w = nullptr, const float* c1_bias = nullptr,
+                             void* y1 = nullptr) {
     auto kern = et == 1 ? stem_fused_kernel<1, TIN> : stem_fused_kernel<0, TIN>;
     {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
@@ -610,14 +614,18 @@ hipError_t launch_stem_fused(const TIN* x, const void* wpk, const float* bias, v
         else
             for (int cand : {28, 14, 7, 4, 2})
                 if (n * (28 / cand) >= 200) { G = cand; break; }
-        auto kern2 = et == 1 ? stem_fused2_kernel<1, TIN> : stem_fused2_kernel<0, TIN>;
+        const bool c1 = c1_w && c1_bias && y1;
+        auto kern2 = c1 ? (et == 1 ? stem_fused2_kernel<1, TIN, true> : stem_fused2_kernel<0, TIN, true>)
+                        : (et == 1 ? stem_fused2_kernel<1, TIN, false> : stem_fused2_kernel<0, TIN, false>);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, SF2_LDS_BYTES);
         if (e != hipSuccess) return e;
         const int strips = n * (28 / G);
         const int grid2 = strips < g_num_cus ? strips : g_num_cus;
-        hipLaunchKernelGGL(kern2, dim3(grid2), dim3(SF_THREADS), SF2_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, strips, G, u8_table);
+        hipLaunchKernelGGL(kern2, dim3(grid2), dim3(SF_THREADS), SF2_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, strips, G, u8_table,
+                           (const __bf16*)c1_w, c1_bias, (__bf16*)y1);
         return hipGetLastError();
     }
+    if (c1_w) return hipErrorInvalidValue;            // the per-pair version has no conv1 stage
     const int tiles = n * 28;
     const int grid = tiles < g_num_cus ? tiles : g_num_cus;       // 128 KB of LDS: one workgroup per CU
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, tiles, u8_table);
@@ -694,6 +702,7 @@ int run_stack(r50_handle* h, const TIN* x, int n, float* out, hipStream_t s, con
     };
     EvRec r{};
     hipError_t e;
+    bool stem_c1 = false;       // layer1.0.conv1 already computed by the stem kernel (into buf[2])
     if (split) {
         char* xp_tail = stem_xp + (size_t)n * STEM_HP * STEM_WP * 8;
         prof_begin(h, s, r, PC_STEM_CONV, 2.0 * n * 112 * 112 * 64 * 147.0, (double)n * (3.0 * 224 * 224 * 4 + 112.0 * 112 * 128 * 2));
@@ -702,8 +711,14 @@ int run_stack(r50_handle* h, const TIN* x, int n, float* out, hipStream_t s, con
         if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem (split): ") + hipGetErrorString(e));
     } else if (h->fused_stem && !(tap && std::string(tap) == "stem")) {
         // conv1 + bn1 + relu + maxpool in one kernel: frame in, (n,56,56,64) out
-        prof_begin(h, s, r, PC_STEM_CONV, 2.0 * n * 112 * 112 * 64 * 147.0, (double)n * (3.0 * 224 * 224 * 4 + 56.0 * 56 * 64 * 2));
-        e = launch_stem_fused(x, h->stem_w, h->convs[0].bias, buf[1], n, s, h->u8_table, et);
+        // ... and, in the strip version, layer1.0.conv1 (1x1, 64 -> 64) of the pooled rows into buf[2] while they are still in LDS
+        const ConvLayer& l1c1 = h->convs[1];
+        stem_c1 = h->fuse_stem_c1 && stem_strip_enabled() && (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16) &&
+                  h->tile_override == 0 && l1c1.ks == 1 && l1c1.stride == 1 && l1c1.cin == 64 && l1c1.cout == 64;
+        prof_begin(h, s, r, PC_STEM_CONV, 2.0 * n * 112 * 112 * 64 * 147.0 + (stem_c1 ? 2.0 * n * 56 * 56 * 64 * 64 : 0.0),
+                   (double)n * (3.0 * 224 * 224 * 4 + 56.0 * 56 * 64 * 2 * (stem_c1 ? 2 : 1)));
+        e = launch_stem_fused(x, h->stem_w, h->convs[0].bias, buf[1], n, s, h->u8_table, et, stem_c1 ? l1c1.w : nullptr,
+                              stem_c1 ? l1c1.bias : nullptr, stem_c1 ? buf[2] : nullptr);
         prof_end(h, s, r);
         if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("stem_fused: ") + hipGetErrorString(e));
         goto after_pool;
@@ -729,7 +744,7 @@ after_pool:
     if (hit("pool", buf[1], 56, 56, 64)) return R50_OK;
 
     int cur = 1, hh = 56, ww = 56;
-    int pre_t1 = -1;            // buffer that already holds the coming block's conv1 output (fused tail), or -1
+    int pre_t1 = stem_c1 ? 2 : -1;      // buffer that already holds the coming block's conv1 output (fused tail / stem), or -1
     size_t li = 1;
     for (int si = 0; si < 4; ++si) {
         const int blocks = kStages[si][1];
@@ -1048,6 +1063,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "tile") h->tile_override = (int)value;
     else if (k == "fused_stem") h->fused_stem = value ? 1 : 0;
     else if (k == "fuse_tail") h->fuse_tail = value ? 1 : 0;
+    else if (k == "fuse_stem_c1") h->fuse_stem_c1 = value ? 1 : 0;
     else if (k == "stem_strip") {          // process-wide (the launcher is shared by the handle and the r50_op_* hooks)
         if (!(value == -1 || value == 0 || (value > 0 && 28 % value == 0))) return fail(h, R50_ERR_INVALID, "stem_strip must be -1, 0 or a divisor of 28");
         g_stem_strip = (int)value;
@@ -1067,6 +1083,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "streams") *value = h->n_streams;
     else if (k == "fused_stem") *value = h->fused_stem;
     else if (k == "fuse_tail") *value = h->fuse_tail;
+    else if (k == "fuse_stem_c1") *value = h->fuse_stem_c1;
     else if (k == "stem_strip") *value = g_stem_strip;
     else if (k == "overlap_ds") *value = h->overlap_ds;
     else if (k == "max_batch") *value = h->max_batch;

@@ -187,6 +187,20 @@ def test_fused_stem_equals_unfused(setup):
             assert torch.equal(bb.layer(xd, "pool"), unfused), g
     finally:
         bb.set_option("stem_strip", 0)
+    # layer1.0.conv1 riding along in the strip kernel: the same bits as its own igemm launch, for every strip length
+    assert bb.get_option("fuse_stem_c1") == 1
+    bb.set_option("fuse_stem_c1", 0)
+    t1_plain = bb.layer(xd, "layer1.0.t1").clone()
+    f_plain = bb.features(xd).clone()
+    bb.set_option("fuse_stem_c1", 1)
+    try:
+        for g in (0, 1, 2, 4, 7, 14, 28):
+            bb.set_option("stem_strip", g)
+            assert torch.equal(bb.layer(xd, "layer1.0.t1"), t1_plain), g
+            assert torch.equal(bb.layer(xd, "pool"), unfused), g
+            assert torch.equal(bb.features(xd), f_plain), g
+    finally:
+        bb.set_option("stem_strip", 0)
     bb.set_option("fused_stem", 0)
     try:
         assert torch.equal(bb.layer(xd, "pool"), unfused)
