@@ -2008,7 +2008,20 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const __bf16* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
     const __bf16* p = x + (size_t)n * HW * C + g * 8;
-    for (int r = 0; r < HW; ++r) {
+    int r = 0;
+    for (; r + 7 <= HW; r += 7) {                      // seven rows in flight, added in row order (HW = 49 = 7 x 7)
+        u32x4 v[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + (size_t)(r + i) * C));
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[2 * e] += unpack_lo_e<ET>(v[i][e]);
+                s[2 * e + 1] += unpack_hi_e<ET>(v[i][e]);
+            }
+    }
+    for (; r < HW; ++r) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(p + (size_t)r * C);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

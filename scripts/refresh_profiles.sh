@@ -1,0 +1,15 @@
+#!/bin/bash
+# End-of-round refresh on the GPU box: full GPU test suite, default bench line, rocprofv3 kernel stats of the same command, per-layer
+# profile, PMC passes (HBM bytes, MFMA utilisation).  Outputs under gpurun_out/; copy the summaries into profiles/.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -k 10 600 python3 -m pytest tests -m gpu -q > gpurun_out/t_final.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/t_final.log
+timeout -k 10 300 python3 bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err || echo "bench failed"
+rm -rf gpurun_out/prof_final
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/prof_final.log 2>&1 || echo "rocprof stats failed"
+timeout -k 10 200 python3 scripts/layer_profile.py > gpurun_out/layer_profile_final.txt 2>&1 || echo "layer profile failed"
+rm -rf gpurun_out/pmcb_FETCH_SIZE gpurun_out/pmcb_WRITE_SIZE
+bash scripts/pmc_bench.sh
+python3 scripts/pmc_bench_summary.py > gpurun_out/pmc_hbm_traffic_final.json
+bash scripts/pmc_bench_mfma.sh
+tail -3 gpurun_out/t_final.log; cut -c1-300 gpurun_out/bench_final.json
