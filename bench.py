@@ -96,6 +96,7 @@ def main() -> None:
     ap.add_argument("--no-fused-stem", action="store_true", help="A/B: run conv1 / maxpool as separate kernels")
     ap.add_argument("--no-fuse-tail", action="store_true", help="A/B: layer1 conv3 and the next conv1 as two igemm launches")
     ap.add_argument("--no-stem-c1", action="store_true", help="A/B: layer1.0.conv1 as its own igemm launch instead of inside the stem kernel")
+    ap.add_argument("--no-ds-cat", action="store_true", help="A/B: downsample conv and conv3 of layer2.0 / 3.0 / 4.0 as separate launches")
     ap.add_argument("--no-overlap-ds", action="store_true", help="A/B: downsample convs on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -135,6 +136,8 @@ def main() -> None:
         bb.set_option("fused_stem", 0)
     if args.no_stem_c1:
         bb.set_option("fuse_stem_c1", 0)
+    if args.no_ds_cat:
+        bb.set_option("fuse_ds_cat", 0)
     if args.no_fuse_tail:
         bb.set_option("fuse_tail", 0)
     if args.no_overlap_ds:

@@ -127,6 +127,12 @@ struct ConvArgs {
     int x_wrap;           // K chunk index at which the X chunk index wraps to 0 again (split: 2*Cin/64; else huge)
     int y_cstride;        // channels per pixel of Y / residual (Cout; 2*Cout in split mode)
     int et;               // element type of operands / activations: 0 = bf16, 1 = fp16 (host-side dispatch only)
+    // Second K source of a 1x1 conv (igemm_ws_kernel only): K = [x (Cin = 64*cc1 channels) | x2 (the rest of cin_chunks)], the
+    // second one read at stride2 from its own tensor -- conv3 and the downsample conv of a stage's first bottleneck as ONE GEMM
+    // against [W3 | Wd].  x2 == nullptr: ordinary conv (cc1 is then huge).
+    const __bf16* x2;     // (N,H2,W2,x2_cstride) or nullptr
+    int H2, W2, stride2, x2_cstride, cc1;
+    unsigned x2_records;
 #if defined(R50_STAMP)    // diagnostic build (scripts/stamp_conv.py): per-wave cycle sums, 8 slots per wave
     unsigned long long* dbg;
 #endif
@@ -490,7 +496,10 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
             __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w), 0, a.w_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(reinterpret_cast<const char*>(a.x) - a.x_back), 0, a.x_records, 0x00020000);
-        unsigned x_voff[XROWS], x_mask[XROWS], w_voff[WROWS];
+        const bool dual = (a.x2 != nullptr);
+        const __amdgpu_buffer_rsrc_t rsrc_x2 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<__bf16*>(dual ? a.x2 : a.x), 0, dual ? a.x2_records : 0u, 0x00020000);
+        unsigned x_voff[XROWS], x_mask[XROWS], w_voff[WROWS], x2_voff[XROWS];
         auto decode_tile = [&](int tile) {
             const int pt = (int)fast_div((unsigned)tile, a.div_ctiles);
             const int c0 = (tile - pt * a.n_ctiles) * BC, p0 = pt * BP;
@@ -498,6 +507,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
             for (int i = 0; i < XROWS; ++i) {
                 const int m = p0 + i * RPPL + srow;
                 unsigned mask = 0u, voff = kOobOffset;
+                x2_voff[i] = kOobOffset;
                 if ((BP_PAD == BP || i * RPPL + srow < BP) && m < a.M) {
                     const int n = (int)fast_div((unsigned)m, a.div_howo);
                     const int r = m - n * a.HoWo;
@@ -505,6 +515,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
                     const int wo = r - ho * a.Wo;
                     const int hc = ho * a.stride, wc = wo * a.stride;
                     voff = (unsigned)(((n * a.H + hc) * a.W + wc) * a.x_cstride + lchunk * 8) * 2u;
+                    if (dual) x2_voff[i] = (unsigned)(((n * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.x2_cstride + lchunk * 8) * 2u;
                     if (a.ks == 1) {
                         mask = 1u;
                     } else {
@@ -542,6 +553,13 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (LDS_AS void*)(sbase + i * PASS_BYTES + lw * 1024), 16, w_voff[i],
                                                          wofs, 0, 0);
 #endif
+            if (i_cc >= a.cc1) {                           // second K source (uniform): its own descriptor, pixels and chunk offset
+                const int x2ofs = __builtin_amdgcn_readfirstlane((i_cc - a.cc1) * 128);
+#pragma unroll
+                for (int i = 0; i < XROWS; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x2, (LDS_AS void*)(sbase + BC * 128 + i * PASS_BYTES + lw * 1024), 16,
+                                                             x2_voff[i], x2ofs, 0, 0);
+            } else {
 #pragma unroll
             for (int i = 0; i < XROWS; ++i) {
 #if defined(R50_ABLATE_OOB) && (R50_ABLATE_OOB & 1)     // diagnostic: every X DMA zero-fills (no L2 traffic for X)
@@ -551,6 +569,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
 #endif
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void*)(sbase + BC * 128 + i * PASS_BYTES + lw * 1024), 16,
                                                          voff, xofs, 0, 0);
+            }
             }
             i_buf = (i_buf == NSTAGE - 1) ? 0 : i_buf + 1;
             i_wofs += 128;

@@ -53,6 +53,9 @@ struct r50_handle {
     hipEvent_t ev_ds_fork = nullptr, ev_ds_join = nullptr;
     int fused_stem = 1;                 // bf16 mode: conv1+bn1+relu+maxpool in one kernel
     int fuse_stem_c1 = 1;               // strip stem kernel also computes layer1.0.conv1
+    int fuse_ds_cat = 1;                // layer2.0 / 3.0 / 4.0: conv3 and the downsample conv as one GEMM over K = [t2 | x at stride 2]
+    __bf16* cat_w[4] = {nullptr, nullptr, nullptr, nullptr};      // per stage: (cout, cmid + cin) = [W3 | Wd], device
+    float* cat_bias[4] = {nullptr, nullptr, nullptr, nullptr};    // b3 + bd (fp32)
     int fuse_tail = 1;                  // bf16 mode, layer1: conv3 + identity + ReLU + the next block's conv1 in one kernel
     int n_streams = 1;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -392,6 +395,7 @@ hipError_t launch_igemm_et(const ConvArgs& a, int tile, hipStream_t s, bool spli
         return launch_igemm_t<0, 128, 128, 2, 2, 2, true>(a, false, s);
     }
     if (tile == 0) tile = auto_tile(a);
+    if (a.x2 && (!(tile & kWsBit) || tile == kTileC64)) return hipErrorInvalidValue;     // two K sources: igemm_ws_kernel only
     const bool pers = (tile & kPersistBit) != 0;
     if (tile == kTileC64) return launch_conv3x3_c64<ET>(a, s);
     if (tile & kWsBit) {
@@ -461,6 +465,7 @@ int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, con
     a.div_wo = make_fast_div((unsigned)a.Wo);
     a.div_ctiles = FastDiv{0u, 0u};
     a.et = 0;
+    a.x2 = nullptr; a.H2 = 0; a.W2 = 0; a.stride2 = 1; a.x2_cstride = 0; a.cc1 = 1 << 30; a.x2_records = 0u;
 #if defined(R50_STAMP)
     a.dbg = nullptr;
 #endif
@@ -568,6 +573,50 @@ int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, 
     prof_end(h, s, r);
     if (e != hipSuccess) return fail(h, R50_ERR_HIP, "igemm launch (" + L.conv_key + "): " + hipGetErrorString(e));
     *ho = a.Ho; *wo = a.Wo;
+    return R50_OK;
+}
+
+// 1x1 conv over two K sources: y = act([W1 | W2] . [x1 ; x2 at stride2] + bias).  x1 (n,h,w,c1) at the output resolution,
+// x2 (n,h2,w2,c2) sampled at (ho*stride2, wo*stride2); wcat (cout, c1 + c2) K-major.  Role-specialised kernel only.
+int fill_conv_args_cat(ConvArgs& a, const void* x1, int n, int h, int w, int c1, const void* x2, int h2, int w2, int c2, int stride2,
+                       const void* wcat, const float* bias, void* y, int cout, int relu) {
+    if (!x2 || c2 <= 0 || c2 % 64 || stride2 < 1 || h2 < 1 || w2 < 1) return R50_ERR_INVALID;
+    if ((h2 - 1) / stride2 + 1 != h || (w2 - 1) / stride2 + 1 != w) return R50_ERR_INVALID;
+    int rc = fill_conv_args(a, x1, n, h, w, c1, wcat, bias, nullptr, y, cout, 1, 1, 0, relu);
+    if (rc) return rc;
+    const long long x2_bytes = (long long)n * h2 * w2 * c2 * 2;
+    if (x2_bytes >= (1ll << 31) || (long long)cout * (c1 + c2) * 2 >= (1ll << 31)) return R50_ERR_INVALID;
+    a.Cin = c1 + c2;
+    a.cin_chunks = (c1 + c2) / 64; a.nk = a.cin_chunks; a.Ktot = c1 + c2;
+    a.w_bytes = (unsigned)((long long)cout * a.Ktot * 2);
+    a.x2 = (const __bf16*)x2; a.H2 = h2; a.W2 = w2; a.stride2 = stride2; a.x2_cstride = c2; a.cc1 = c1 / 64;
+    a.x2_records = (unsigned)x2_bytes;
+    return R50_OK;
+}
+int cat_tile(const ConvArgs& a, int tile) {          // tile id for a two-source conv: role-specialised variants only
+    if (tile == 0) {
+        if (a.N >= 48) {                               // measured at batch 256 (scripts/time_cat.py, profiles/r01_time_cat.txt)
+            if (a.Cout % 256 == 0) return kWsBit | 3;      // 256x128, 8 consumer waves: fastest of the five at all three shapes
+        }
+        for (int c : {kWsBit | 8, kWsBit | 1, kWsBit | 9})
+            if (tiles_of(a, c) >= 200) return c;
+        return kWsBit | 9;
+    }
+    return (tile & kWsBit) ? tile : -1;
+}
+int run_conv_cat(r50_handle* h, int si, const ConvLayer& c3, const ConvLayer& cd, const __bf16* t2, const __bf16* xin, int n, int h2, int w2,
+                 int hin, int win, __bf16* y, hipStream_t s) {
+    ConvArgs a;
+    int rc = fill_conv_args_cat(a, t2, n, h2, w2, c3.cin, xin, hin, win, cd.cin, cd.stride, h->cat_w[si], h->cat_bias[si], y, c3.cout, 1);
+    if (rc) return fail(h, rc, "two-source conv args invalid for " + c3.conv_key);
+    a.et = (h->precision == R50_PREC_FP16) ? 1 : 0;
+    EvRec r{};
+    const double flops = 2.0 * a.M * (double)a.Cout * a.Ktot;
+    const double bytes = 2.0 * ((double)a.M * (c3.cin + cd.cin) + (double)a.M * a.Cout + (double)a.Cout * a.Ktot);
+    prof_begin(h, s, r, PC_IGEMM, flops, bytes, (int)(&c3 - &h->convs[0]));
+    hipError_t e = launch_igemm(a, cat_tile(a, 0), s, false);
+    prof_end(h, s, r);
+    if (e != hipSuccess) return fail(h, R50_ERR_HIP, "igemm launch (" + c3.conv_key + " + downsample): " + hipGetErrorString(e));
     return R50_OK;
 }
 
@@ -770,12 +819,17 @@ after_pool:
             const bool fuse_ok = !split && (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16) && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
                                  nx->ks == 1 && nx->stride == 1;
             const bool fuse2 = fuse_ok && c3.cin == 128 && c3.cout == 512 && nx->cin == 512 && nx->cout == 128;   // layer2 shapes
-            const bool fuse = (fuse_ok && c3.cin == 64 && c3.cout == 256 && nx->cin == 256 && (nx->cout == 64 || nx->cout == 128)) ||
-                              fuse2;
             const ConvLayer* cdp = (b == 0) ? &h->convs[li + 3] : nullptr;
+            // layer2.0 / 3.0 / 4.0: conv3 + downsample + add + ReLU as ONE 1x1 conv over K = [t2 | block input at the block's stride]
+            // against [W3 | Wd]: the downsample tensor is never written or read back, and there is one launch instead of two.
+            // It takes precedence over the layer2 tail fusion in layer2.0 (whose identity would be that downsample tensor).
+            const bool cat_ds = (b == 0) && si >= 1 && !split && h->fuse_ds_cat && h->cat_w[si] && h->tile_override == 0 &&
+                                cdp && cdp->ks == 1 && c3.ks == 1 && !(tap && p + ".ds" == tap);
+            const bool fuse = !cat_ds && ((fuse_ok && c3.cin == 64 && c3.cout == 256 && nx->cin == 256 && (nx->cout == 64 || nx->cout == 128)) ||
+                                          fuse2);
             const bool fuse_ds = fuse && cdp && cdp->ks == 1 && cdp->stride == 1 && cdp->cin == 64 && cdp->cout == 256 &&
                                  !(tap && p + ".ds" == tap);
-            const bool ds_side = (b == 0) && h->overlap_ds && !h->profile && !tap && !fuse_ds;
+            const bool ds_side = (b == 0) && h->overlap_ds && !h->profile && !tap && !fuse_ds && !cat_ds;
             hipStream_t sd = s;
             const __bf16* idn = buf[cur];
             int rc;
@@ -803,7 +857,7 @@ after_pool:
             rc = run_conv(h, c2, buf[fr[0]], n, h1, w1, nullptr, buf[fr[1]], 1, s, &h2, &w2);
             if (rc) return rc;
             if (hit(p + ".t2", buf[fr[1]], h2, w2, c2.cout)) return R50_OK;
-            if (b == 0 && !ds_side && !fuse_ds) {
+            if (b == 0 && !ds_side && !fuse_ds && !cat_ds) {
                 const ConvLayer& cd = h->convs[li + 3];
                 int hd, wd;
                 rc = run_conv(h, cd, buf[cur], n, hh, ww, nullptr, buf[fr[2]], 0, s, &hd, &wd);
@@ -828,6 +882,10 @@ after_pool:
                 if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_tail launch (" + c3.conv_key + "): " + hipGetErrorString(e));
                 h3 = h2; w3 = w2;
                 pre_t1 = fr[0];
+            } else if (cat_ds) {
+                rc = run_conv_cat(h, si, c3, *cdp, buf[fr[1]], buf[cur], n, h2, w2, hh, ww, buf[fr[3]], s);
+                if (rc) return rc;
+                h3 = h2; w3 = w2;
             } else {
                 rc = run_conv(h, c3, buf[fr[1]], n, h2, w2, idn, buf[fr[3]], 1, s, &h3, &w3);
                 if (rc) return rc;
@@ -850,6 +908,11 @@ void free_all(r50_handle* h) {
         if (L.w) (void)hipFree(L.w);
         if (L.bias) (void)hipFree(L.bias);
         L.w = nullptr; L.bias = nullptr;
+    }
+    for (int i = 0; i < 4; ++i) {
+        if (h->cat_w[i]) (void)hipFree(h->cat_w[i]);
+        if (h->cat_bias[i]) (void)hipFree(h->cat_bias[i]);
+        h->cat_w[i] = nullptr; h->cat_bias[i] = nullptr;
     }
     if (h->stem_w) (void)hipFree(h->stem_w);
     if (h->stem_xp) (void)hipFree(h->stem_xp);
@@ -997,6 +1060,9 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
     };
     std::vector<float> wf, bf;
     std::vector<uint16_t> pk;
+    // [W3 | Wd] and b3 + bd of layer2.0 / layer3.0 / layer4.0 (16-bit precisions): convs are stored c1, c2, c3, ds per first block
+    const bool want_cat = (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16);
+    std::map<size_t, std::pair<std::vector<uint16_t>, std::vector<float>>> kept;       // conv index -> (packed weights, bias)
     for (size_t i = 0; i < h->convs.size(); ++i) {
         ConvLayer& L = h->convs[i];
         const float *w, *g, *b, *m, *v;
@@ -1025,6 +1091,30 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
             else pack_ohwi_bf16(wf.data(), L.cout, L.cin, L.ks, pk);
             if (!L.w) HIP_TRY(h, hipMalloc((void**)&L.w, pk.size() * 2));
             HIP_TRY(h, hipMemcpy(L.w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+            if (want_cat && L.ks == 1 && (L.conv_key.find(".0.conv3") != std::string::npos || L.conv_key.find(".downsample.0") != std::string::npos))
+                kept[i] = {pk, bf};
+        }
+    }
+    if (want_cat) {
+        size_t li = 1;
+        for (int si = 0; si < 4; ++si) {
+            const size_t i3 = li + 2, id = li + 3;
+            if (si >= 1 && kept.count(i3) && kept.count(id)) {
+                const ConvLayer &c3 = h->convs[i3], &cd = h->convs[id];
+                const int k1 = c3.cin, k2 = cd.cin, co = c3.cout;
+                std::vector<uint16_t> cat((size_t)co * (k1 + k2));
+                std::vector<float> cb(co);
+                for (int o = 0; o < co; ++o) {
+                    std::memcpy(&cat[(size_t)o * (k1 + k2)], &kept[i3].first[(size_t)o * k1], (size_t)k1 * 2);
+                    std::memcpy(&cat[(size_t)o * (k1 + k2) + k1], &kept[id].first[(size_t)o * k2], (size_t)k2 * 2);
+                    cb[o] = kept[i3].second[o] + kept[id].second[o];
+                }
+                if (!h->cat_w[si]) HIP_TRY(h, hipMalloc((void**)&h->cat_w[si], cat.size() * 2));
+                if (!h->cat_bias[si]) HIP_TRY(h, hipMalloc((void**)&h->cat_bias[si], co * sizeof(float)));
+                HIP_TRY(h, hipMemcpy(h->cat_w[si], cat.data(), cat.size() * 2, hipMemcpyHostToDevice));
+                HIP_TRY(h, hipMemcpy(h->cat_bias[si], cb.data(), co * sizeof(float), hipMemcpyHostToDevice));
+            }
+            li += 4 + 3 * (kStages[si][1] - 1);
         }
     }
     h->loaded = true;
@@ -1064,6 +1154,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "fused_stem") h->fused_stem = value ? 1 : 0;
     else if (k == "fuse_tail") h->fuse_tail = value ? 1 : 0;
     else if (k == "fuse_stem_c1") h->fuse_stem_c1 = value ? 1 : 0;
+    else if (k == "fuse_ds_cat") h->fuse_ds_cat = value ? 1 : 0;
     else if (k == "stem_strip") {          // process-wide (the launcher is shared by the handle and the r50_op_* hooks)
         if (!(value == -1 || value == 0 || (value > 0 && 28 % value == 0))) return fail(h, R50_ERR_INVALID, "stem_strip must be -1, 0 or a divisor of 28");
         g_stem_strip = (int)value;
@@ -1084,6 +1175,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "fused_stem") *value = h->fused_stem;
     else if (k == "fuse_tail") *value = h->fuse_tail;
     else if (k == "fuse_stem_c1") *value = h->fuse_stem_c1;
+    else if (k == "fuse_ds_cat") *value = h->fuse_ds_cat;
     else if (k == "stem_strip") *value = g_stem_strip;
     else if (k == "overlap_ds") *value = h->overlap_ds;
     else if (k == "max_batch") *value = h->max_batch;
@@ -1184,6 +1276,18 @@ static int op_conv2d_et(int et, const void* x, int n, int h, int w, int cin, con
 #endif
     hipError_t e = launch_igemm(a, tile, (hipStream_t)stream);
     if (e != hipSuccess) return fail(nullptr, R50_ERR_HIP, std::string("r50_op_conv2d: ") + hipGetErrorString(e));
+    return R50_OK;
+}
+
+int r50_op_conv1x1_cat(const void* x1, int n, int h, int w, int c1, const void* x2, int h2, int w2, int c2, int stride2, const void* wcat,
+                       const float* bias, void* y, int cout, int relu, int tile, int et, void* stream) {
+    ConvArgs a;
+    int rc = fill_conv_args_cat(a, x1, n, h, w, c1, x2, h2, w2, c2, stride2, wcat, bias, y, cout, relu);
+    if (rc || (et != 0 && et != 1)) return fail(nullptr, R50_ERR_INVALID, "r50_op_conv1x1_cat: invalid arguments");
+    a.et = et;
+    hipError_t e = launch_igemm(a, cat_tile(a, tile), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
+                                     std::string("r50_op_conv1x1_cat: ") + hipGetErrorString(e));
     return R50_OK;
 }
 

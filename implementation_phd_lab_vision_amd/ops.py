@@ -77,6 +77,28 @@ def conv2d_bf16(x: torch.Tensor, w_ohwi: torch.Tensor, bias: torch.Tensor, strid
     return y
 
 
+def conv1x1_cat(x1: torch.Tensor, x2: torch.Tensor, stride2: int, wcat: torch.Tensor, bias: torch.Tensor, relu: bool = True,
+                tile: int = TILE_AUTO) -> torch.Tensor:
+    """``act([W1 | W2] . [x1 ; x2 at stride2] + bias)``: conv3 + downsample + add + ReLU of a stage's first bottleneck as one 1x1
+    conv.  x1 (N,H,W,C1), x2 (N,H2,W2,C2) with (H2-1)//stride2+1 == H, wcat (Cout, C1+C2), all bf16 or all fp16; bias fp32."""
+    et = x1.dtype
+    if et not in (torch.bfloat16, torch.float16):
+        raise ValueError("conv1x1_cat: x1 must be bf16 or fp16")
+    _need(x1, et, "x1"); _need(x2, et, "x2"); _need(wcat, et, "wcat"); _need(bias, torch.float32, "bias")
+    n, h, w, c1 = x1.shape
+    n2, h2, w2, c2 = x2.shape
+    cout = wcat.shape[0]
+    if n2 != n or tuple(wcat.shape) != (cout, c1 + c2) or bias.numel() != cout:
+        raise ValueError("conv1x1_cat: inconsistent shapes")
+    y = torch.empty((n, h, w, cout), dtype=et, device=x1.device)
+    with torch.cuda.device(x1.device):
+        rc = _lib.load_library().r50_op_conv1x1_cat(x1.data_ptr(), n, h, w, c1, x2.data_ptr(), h2, w2, c2, int(stride2), wcat.data_ptr(),
+                                                    bias.data_ptr(), y.data_ptr(), cout, int(relu), int(tile),
+                                                    1 if et == torch.float16 else 0, _stream(x1))
+    _lib.check(rc, None, "r50_op_conv1x1_cat")
+    return y
+
+
 def bneck_tail_bf16(y2: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, identity: torch.Tensor, w1: torch.Tensor,
                     b1: torch.Tensor, wd: Optional[torch.Tensor] = None, bd: Optional[torch.Tensor] = None):
     """Fused tail of a bottleneck: ``out = relu(conv3(y2) + b3 + identity)`` and the next block's

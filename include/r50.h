@@ -134,6 +134,13 @@ int r50_op_conv2d_f16(const void* x_nhwc_f16, int n, int h, int w, int cin, cons
                   const float* bias_f32, const void* residual_nhwc_f16, void* y_nhwc_f16,
                   int cout, int ksize, int stride, int pad, int relu, int tile, void* stream);
 
+/* 1x1 conv over TWO K sources, the form the library runs conv3 + downsample + add + ReLU of a stage's first bottleneck in
+ * (torchvision Bottleneck.forward: `out = conv3(out); identity = downsample(x); out += identity; relu`): y = act([W1 | W2] .
+ * [x1 ; x2 sampled at stride2] + bias).  x1 (n,h,w,c1) at the output resolution, x2 (n,h2,w2,c2) with (h2-1)/stride2+1 == h;
+ * wcat (cout, c1+c2) K-major; c1, c2, cout multiples of 64.  tile: 0 = auto or a role-specialised tile id (64|...). et: 0 bf16, 1 fp16. */
+int r50_op_conv1x1_cat(const void* x1, int n, int h, int w, int c1, const void* x2, int h2, int w2, int c2, int stride2,
+                       const void* wcat, const float* bias_f32, void* y, int cout, int relu, int tile, int et, void* stream);
+
 /* Stem: fp32 NCHW frames -> conv 7x7 s2 p3 (+folded bn1 bias) + ReLU -> (n,112,112,64) bf16 NHWC.
  * w_oihw_f32: (64,3,7,7) fp32 *already folded*, host pointer; bias_f32: device pointer (64).
  * scratch_dev: at least r50_stem_scratch_bytes(n) bytes of device memory. */

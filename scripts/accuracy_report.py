@@ -9,12 +9,12 @@ _lib.build_library()
 sd = synthetic_state_dict(0); x = synthetic_frames(8, seed=1234)
 f64 = O.forward_reference(sd, x, dtype=torch.float64).flatten(1)
 f32 = O.forward_reference(sd, x).flatten(1)
-emu = O.forward_bf16_emulated(sd, x)
+emu = O.forward_bf16_emulated(sd, x, fused_ds=True)
 print("oracle fp32 vs fp64      : max per-frame rel-L2 %.3e" % float(O.per_row_rel_l2(f32, f64).max()))
 print("oracle bf16-emu vs fp64  : max per-frame rel-L2 %.3e" % float(O.per_row_rel_l2(emu, f64).max()))
 emu2 = O.forward_bf16_emulated(sd, x, weight_terms=2)
 print("oracle bf16w2-emu vs fp64: max per-frame rel-L2 %.3e" % float(O.per_row_rel_l2(emu2, f64).max()))
-emu16 = O.forward_bf16_emulated(sd, x, fmt="fp16")
+emu16 = O.forward_bf16_emulated(sd, x, fmt="fp16", fused_ds=True)
 print("oracle fp16-emu vs fp64  : max per-frame rel-L2 %.3e" % float(O.per_row_rel_l2(emu16, f64).max()))
 for prec in ("bf16", "fp16", "bf16w2", "fp32x"):
     bb = ResNet50Backbone(state_dict=sd, max_batch=8, precision=prec).to("cuda:0").eval()

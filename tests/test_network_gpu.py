@@ -29,9 +29,9 @@ def setup(lib_built):
     sd = synthetic_state_dict(0)
     x = synthetic_frames(4, seed=1234)
     taps = {}
-    feats_emu = O.forward_bf16_emulated(sd, x, taps=taps)
+    feats_emu = O.forward_bf16_emulated(sd, x, taps=taps, fused_ds=True)
     taps32 = {}
-    O.forward_bf16_emulated(sd, x, taps=taps32, acc_dtype=torch.float32)
+    O.forward_bf16_emulated(sd, x, taps=taps32, acc_dtype=torch.float32, fused_ds=True)
     drift = {k: O.rel_l2(taps32[k], taps[k]) for k in taps}
     feats_ref = O.forward_reference(sd, x).flatten(1)
     bb = ResNet50Backbone(state_dict=sd, max_batch=8).to("cuda:0").eval()
@@ -50,10 +50,13 @@ def test_named_activations_match_emulated_oracle(setup):
         assert r < max(1e-4, 3.0 * drift[name]), f"{name}: rel-L2 {r} (emulation drift {drift[name]})"
 
 
-def test_every_conv_on_shared_inputs(setup):
+@pytest.mark.parametrize("ds_cat", [1, 0], ids=["ds_in_conv3", "ds_separate"])
+def test_every_conv_on_shared_inputs(setup, ds_cat):
     """All 52 bottleneck convs, each checked in isolation: the oracle's fused conv is fed the DEVICE's
-    input activation (and residual), so no drift accumulates and the 1-ulp bar applies."""
-    from oracle.resnet50_oracle import conv_bias_act_emulated, folded
+    input activation (and residual), so no drift accumulates and the 1-ulp bar applies.  ds_cat = 1 (the default): in
+    layer2.0 / 3.0 / 4.0 conv3 and the downsample conv are one accumulation over two K sources, checked as such (the
+    downsample conv alone is still checked through its tap); ds_cat = 0: the two launches."""
+    from oracle.resnet50_oracle import conv_bias_act_emulated, conv_cat_emulated, folded
     from tests.test_kernels_gpu import _check_bf16
     bb, x, (_taps, _drift, sd), _, _ = setup
     xd = x[:2].to("cuda:0")
@@ -64,31 +67,39 @@ def test_every_conv_on_shared_inputs(setup):
     def nchw(t):
         return t.float().cpu().permute(0, 3, 1, 2).contiguous()
 
-    prev = "pool"
-    n_checked = 0
-    for si, (blocks, stride) in enumerate(((3, 1), (4, 2), (6, 2), (3, 2)), start=1):
-        for b in range(blocks):
-            p = f"layer{si}.{b}"
-            s = stride if b == 0 else 1
-            x_in = nchw(dev(prev))
-            t1, t2, out = dev(p + ".t1"), dev(p + ".t2"), dev(p)
-            w, bias = folded(sd, p + ".conv1", p + ".bn1")
-            _check_bf16(t1, conv_bias_act_emulated(x_in, w, bias, 1, 0, True), p + ".conv1")
-            w, bias = folded(sd, p + ".conv2", p + ".bn2")
-            _check_bf16(t2, conv_bias_act_emulated(nchw(t1), w, bias, s, 1, True), p + ".conv2")
-            if b == 0:
-                ds = dev(p + ".ds")
-                w, bias = folded(sd, p + ".downsample.0", p + ".downsample.1")
-                _check_bf16(ds, conv_bias_act_emulated(x_in, w, bias, s, 0, False), p + ".downsample")
-                idn = nchw(ds)
-                n_checked += 1
-            else:
-                idn = x_in
-            w, bias = folded(sd, p + ".conv3", p + ".bn3")
-            _check_bf16(out, conv_bias_act_emulated(nchw(t2), w, bias, 1, 0, True, residual_bf=idn), p + ".conv3")
-            n_checked += 3
-            prev = p
-    assert n_checked == 52
+    assert bb.get_option("fuse_ds_cat") == 1
+    bb.set_option("fuse_ds_cat", ds_cat)
+    try:
+        prev = "pool"
+        n_checked = 0
+        for si, (blocks, stride) in enumerate(((3, 1), (4, 2), (6, 2), (3, 2)), start=1):
+            for b in range(blocks):
+                p = f"layer{si}.{b}"
+                s = stride if b == 0 else 1
+                x_in = nchw(dev(prev))
+                t1, t2, out = dev(p + ".t1"), dev(p + ".t2"), dev(p)
+                w, bias = folded(sd, p + ".conv1", p + ".bn1")
+                _check_bf16(t1, conv_bias_act_emulated(x_in, w, bias, 1, 0, True), p + ".conv1")
+                w, bias = folded(sd, p + ".conv2", p + ".bn2")
+                _check_bf16(t2, conv_bias_act_emulated(nchw(t1), w, bias, s, 1, True), p + ".conv2")
+                if b == 0:
+                    ds = dev(p + ".ds")
+                    wd, bd = folded(sd, p + ".downsample.0", p + ".downsample.1")
+                    _check_bf16(ds, conv_bias_act_emulated(x_in, wd, bd, s, 0, False), p + ".downsample")
+                    idn = nchw(ds)
+                    n_checked += 1
+                else:
+                    idn = x_in
+                w, bias = folded(sd, p + ".conv3", p + ".bn3")
+                if b == 0 and si >= 2 and ds_cat:
+                    _check_bf16(out, conv_cat_emulated(nchw(t2), w, bias, x_in, wd, bd, s), p + ".conv3+downsample")
+                else:
+                    _check_bf16(out, conv_bias_act_emulated(nchw(t2), w, bias, 1, 0, True, residual_bf=idn), p + ".conv3")
+                n_checked += 3
+                prev = p
+        assert n_checked == 52
+    finally:
+        bb.set_option("fuse_ds_cat", 1)
 
 
 def test_features_match_oracles(setup):
@@ -312,7 +323,7 @@ def test_fp16_precision(lib_built):
     assert torch.isfinite(got).all()
     ref = O.forward_reference(sd, x, dtype=torch.float64).float()
     taps = {}
-    emu = O.forward_bf16_emulated(sd, x, taps=taps, fmt="fp16")
+    emu = O.forward_bf16_emulated(sd, x, taps=taps, fmt="fp16", fused_ds=True)
     r_ref, r_emu = O.per_row_rel_l2(got, ref), O.per_row_rel_l2(got, emu)
     assert float(r_ref.max()) < 1e-3, f"fp16 vs fp64 reference: {r_ref.tolist()}"
     assert float(r_ref.max()) < 5e-4, f"fp16 should sit well inside the tolerance: {r_ref.tolist()}"
