@@ -42,6 +42,26 @@ __device__ __forceinline__ f32x4 mfma_e(bf16x8 a, bf16x8 b, f32x4 c) {
     if constexpr (ET == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+// ET 2 = fp8 (OCP e4m3), igemm_ws_kernel only (BASELINE configs[4]).  One byte per element: a 128-byte LDS row holds 128 values of K
+// instead of 64, everything the loaders do is unchanged (the host describes the tensors in 2-byte units), and the two 16-byte
+// fragments a lane reads per row-step are together the 32-byte operand of ONE v_mfma_scale_f32_16x16x128_f8f6f4 (K = 128; both
+// block scales 2^0) -- twice the multiply-adds per LDS byte and per issue slot of the 16-bit path.  A and B fragments are read
+// with the same (lane, byte) -> chunk mapping, so whatever order the instruction assigns to K inside a lane, both operands agree.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+__device__ __forceinline__ f32x4 mfma_fp8_k128(bf16x8 a0, bf16x8 a1, bf16x8 b0, bf16x8 b1, f32x4 c) {
+    const u32x4 al = __builtin_bit_cast(u32x4, a0), ah = __builtin_bit_cast(u32x4, a1);
+    const u32x4 bl = __builtin_bit_cast(u32x4, b0), bh = __builtin_bit_cast(u32x4, b1);
+    const i32x8 a = {(int)al[0], (int)al[1], (int)al[2], (int)al[3], (int)ah[0], (int)ah[1], (int)ah[2], (int)ah[3]};
+    const i32x8 b = {(int)bl[0], (int)bl[1], (int)bl[2], (int)bl[3], (int)bh[0], (int)bh[1], (int)bh[2], (int)bh[3]};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+__device__ __forceinline__ unsigned pack4_fp8(float v0, float v1, float v2, float v3) {   // saturating at +-448 (e4m3 max)
+    v0 = __builtin_amdgcn_fmed3f(v0, -448.0f, 448.0f); v1 = __builtin_amdgcn_fmed3f(v1, -448.0f, 448.0f);
+    v2 = __builtin_amdgcn_fmed3f(v2, -448.0f, 448.0f); v3 = __builtin_amdgcn_fmed3f(v3, -448.0f, 448.0f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v2, v3, w, true);
+    return (unsigned)w;
+}
 template <int ET>
 __device__ __forceinline__ unsigned int pack2_e(float lo, float hi) {     // two fp32 -> packed pair, round to nearest even
     if constexpr (ET == 0) {
@@ -127,6 +147,7 @@ struct ConvArgs {
     int x_wrap;           // K chunk index at which the X chunk index wraps to 0 again (split: 2*Cin/64; else huge)
     int y_cstride;        // channels per pixel of Y / residual (Cout; 2*Cout in split mode)
     int et;               // element type of operands / activations: 0 = bf16, 1 = fp16 (host-side dispatch only)
+    float oscale, rscale; // fp8 only: y = fp8(act(acc * oscale + residual * rscale)); bias arrives divided by the dequantisation scale
     // Second K source of a 1x1 conv (igemm_ws_kernel only): K = [x (Cin = 64*cc1 channels) | x2 (the rest of cin_chunks)], the
     // second one read at stride2 from its own tensor -- conv3 and the downsample conv of a stage's first bottleneck as ONE GEMM
     // against [W3 | Wd].  x2 == nullptr: ordinary conv (cc1 is then huge).
@@ -634,7 +655,8 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
         const int pix_lane = wave_p * NR * 16 + fr;
         int c_tile = first, c_k = 0, c_buf = 0;
         unsigned y_voff = 0u;
-        const unsigned y_rowstep = (unsigned)(16 * a.y_cstride * 2);
+        constexpr unsigned ESZ = (ET == 2) ? 1u : 2u;  // bytes per element of Y / residual
+        const unsigned y_rowstep = (unsigned)(16 * a.y_cstride) * ESZ;
 
         // The bias of the NEXT tile is fetched before the epilogue's stores go out: vmcnt retires in order, so a
         // bias load issued behind 28 stores would wait for every one of them to be acknowledged.
@@ -651,7 +673,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
         auto tile_begin = [&]() {
             const int pt = (int)fast_div((unsigned)c_tile, a.div_ctiles);
             const int c0 = (c_tile - pt * a.n_ctiles) * BC, p0 = pt * BP;
-            y_voff = (unsigned)((p0 + pix_lane) * a.y_cstride + c0 + cout_lane) * 2u;
+            y_voff = (unsigned)((p0 + pix_lane) * a.y_cstride + c0 + cout_lane) * ESZ;
 #pragma unroll
             for (int t = 0; t < MR / 2; ++t) {
                 const f32x4 b_lo = bias_reg[2 * t];
@@ -660,8 +682,14 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
                 for (int j = 0; j < NR; ++j) {
                     acc[2 * t][j] = b_lo;
                     acc[2 * t + 1][j] = b_hi;
-                    if constexpr (PREFETCH_RES) if (has_res)
-                        res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, 0);
+                    if constexpr (PREFETCH_RES) if (has_res) {
+                        if constexpr (ET == 2) {
+                            const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_r, y_voff + j * y_rowstep + 32 * t, 0, 0);
+                            res_reg[t][j] = (u32x4){r2[0], r2[1], 0u, 0u};
+                        } else {
+                            res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, 0);
+                        }
+                    }
                 }
             }
         };
@@ -678,6 +706,12 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
 #pragma unroll
                 for (int m = 0; m < MR; ++m) wf[kk][m] = *reinterpret_cast<const bf16x8*>(sbase + w_frag + m * 2048 + ph);
             }
+            if constexpr (ET == 2) {                        // fp8: the row-step's two fragments are one K = 128 operand
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) acc[m][j] = mfma_fp8_k128(wf[0][m], wf[1][m], xf[0][j], xf[1][j], acc[m][j]);
+            } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -689,8 +723,9 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
 #else
                         acc[m][j] = mfma_e<ET>(wf[kk][m], xf[kk][j], acc[m][j]);
 #endif
+            }
 #if !defined(R50_ABLATE_MFMA)
-            if constexpr (NCONS + NLOAD <= 8) {     // 2 waves per SIMD: 256 registers, room for both halves' fragments
+            if constexpr (NCONS + NLOAD <= 8 && ET != 2) {     // 2 waves per SIMD: 256 registers, room for both halves' fragments
                 __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MR + NR), 0);   // every LDS read of the step ...
                 __builtin_amdgcn_sched_group_barrier(0x008, 2 * MR * NR, 0);     // ... then the MFMAs
             }
@@ -702,7 +737,27 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
                     f32x4 lo = acc[2 * t][j], hi = acc[2 * t + 1][j];
-                    const unsigned voff = y_voff + j * y_rowstep + 64 * t;
+                    const unsigned voff = y_voff + j * y_rowstep + 32 * ESZ * t;
+                    if constexpr (ET == 2) {                // fp8: dequantise, add the residual, ReLU, requantise, one 8-byte store
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { lo[e] *= a.oscale; hi[e] *= a.oscale; }
+                        if (has_res) {
+                            u32x2 r;
+                            if constexpr (PREFETCH_RES) r = (u32x2){res_reg[t][j][0], res_reg[t][j][1]};
+                            else r = __builtin_amdgcn_raw_buffer_load_b64(rsrc_r, voff, 0, 0);
+                            lo[0] += __builtin_amdgcn_cvt_f32_fp8((int)r[0], 0) * a.rscale; lo[1] += __builtin_amdgcn_cvt_f32_fp8((int)r[0], 1) * a.rscale;
+                            lo[2] += __builtin_amdgcn_cvt_f32_fp8((int)r[0], 2) * a.rscale; lo[3] += __builtin_amdgcn_cvt_f32_fp8((int)r[0], 3) * a.rscale;
+                            hi[0] += __builtin_amdgcn_cvt_f32_fp8((int)r[1], 0) * a.rscale; hi[1] += __builtin_amdgcn_cvt_f32_fp8((int)r[1], 1) * a.rscale;
+                            hi[2] += __builtin_amdgcn_cvt_f32_fp8((int)r[1], 2) * a.rscale; hi[3] += __builtin_amdgcn_cvt_f32_fp8((int)r[1], 3) * a.rscale;
+                        }
+                        if (a.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
+                        }
+                        const u32x2 o8 = (u32x2){pack4_fp8(lo[0], lo[1], lo[2], lo[3]), pack4_fp8(hi[0], hi[1], hi[2], hi[3])};
+                        __builtin_amdgcn_raw_buffer_store_b64(o8, rsrc_y, voff, 0, 0);
+                        continue;
+                    }
                     if (has_res) {
                         u32x4 r;
                         if constexpr (PREFETCH_RES) r = res_reg[t][j];

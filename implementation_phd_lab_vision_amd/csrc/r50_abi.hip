@@ -429,6 +429,24 @@ hipError_t launch_igemm(const ConvArgs& a, int tile, hipStream_t s, bool split =
     return a.et == 1 ? launch_igemm_et<1>(a, tile, s, split) : launch_igemm_et<0>(a, tile, s, split);
 }
 
+// fp8 (e4m3) operands: role-specialised kernel only, element type 2 (kernels.h)
+hipError_t launch_igemm_fp8(const ConvArgs& a, int tile, hipStream_t s) {
+    if (tile == 0) {
+        tile = kWsBit | 9;
+        for (int c : {kWsBit | 3, kWsBit | 8, kWsBit | 1})
+            if (tiles_of(a, c) >= 200) { tile = c; break; }
+    }
+    if (!(tile & kWsBit) || tile == kTileC64) return hipErrorInvalidValue;
+    switch (tile & (kPersistBit - 1)) {
+        case 1: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_ws_t<2, 128, 128, 2, 2, 4, 4>(a, s);
+        case 3: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_ws_t<2, 256, 128, 4, 2, 4, 3>(a, s);
+        case 4: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_ws_t<2, 128, 224, 2, 2, 4, 3>(a, s);
+        case 8: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_ws_t<2, 128, 224, 4, 2, 4, 3>(a, s);
+        case 9: return launch_igemm_ws_t<2, 64, 224, 2, 2, 4, 4>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, const void* wt, const float* bias,
                    const void* res, void* y, int cout, int ks, int stride, int pad, int relu, bool split = false, bool w2 = false) {
     if (!x || !wt || !bias || !y) return R50_ERR_INVALID;
@@ -465,6 +483,7 @@ int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, con
     a.div_wo = make_fast_div((unsigned)a.Wo);
     a.div_ctiles = FastDiv{0u, 0u};
     a.et = 0;
+    a.oscale = 1.0f; a.rscale = 1.0f;
     a.x2 = nullptr; a.H2 = 0; a.W2 = 0; a.stride2 = 1; a.x2_cstride = 0; a.cc1 = 1 << 30; a.x2_records = 0u;
 #if defined(R50_STAMP)
     a.dbg = nullptr;
@@ -1276,6 +1295,21 @@ static int op_conv2d_et(int et, const void* x, int n, int h, int w, int cin, con
 #endif
     hipError_t e = launch_igemm(a, tile, (hipStream_t)stream);
     if (e != hipSuccess) return fail(nullptr, R50_ERR_HIP, std::string("r50_op_conv2d: ") + hipGetErrorString(e));
+    return R50_OK;
+}
+
+int r50_op_conv2d_fp8(const void* x, int n, int h, int w, int cin, const void* wt, const float* bias_scaled, const void* res, void* y,
+                      int cout, int ksize, int stride, int pad, int relu, float oscale, float rscale, int tile, void* stream) {
+    if (cin <= 0 || cin % 128) return fail(nullptr, R50_ERR_INVALID, "r50_op_conv2d_fp8: cin must be a multiple of 128");
+    ConvArgs a;
+    // the loaders move bytes: described in 2-byte units, an fp8 tensor with cin channels is a 16-bit tensor with cin / 2
+    int rc = fill_conv_args(a, x, n, h, w, cin / 2, wt, bias_scaled, res, y, cout, ksize, stride, pad, relu);
+    if (rc) return fail(nullptr, rc, "r50_op_conv2d_fp8: invalid arguments");
+    a.y_bytes = (unsigned)((long long)a.M * cout);       // one byte per output element
+    a.et = 2; a.oscale = oscale; a.rscale = rscale;
+    hipError_t e = launch_igemm_fp8(a, tile, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
+                                     std::string("r50_op_conv2d_fp8: ") + hipGetErrorString(e));
     return R50_OK;
 }
 

@@ -77,6 +77,38 @@ def conv2d_bf16(x: torch.Tensor, w_ohwi: torch.Tensor, bias: torch.Tensor, strid
     return y
 
 
+FP8 = torch.float8_e4m3fn        # OCP e4m3: what gfx950's fp8 MFMA and conversions use
+FP8_MAX = 448.0
+
+
+def conv2d_fp8(x: torch.Tensor, sx: float, w_ohwi: torch.Tensor, sw: float, bias: torch.Tensor, sy: float, stride: int = 1, pad: int = 0,
+               relu: bool = True, residual: Optional[torch.Tensor] = None, sr: float = 1.0, tile: int = TILE_AUTO) -> torch.Tensor:
+    """fp8 conv (BASELINE configs[4]), kernel level: x (N,H,W,Cin) / w (Cout,k,k,Cin) / residual / result in ``float8_e4m3fn`` with
+    per-tensor scales (real = stored * scale), bias fp32 in real units -> y (N,Ho,Wo,Cout) fp8 with scale ``sy``:
+    ``y = fp8(act(sx*sw * sum(x*w) + bias + sr*residual) / sy)``, fp32 accumulation on the K = 128 scaled fp8 MFMA."""
+    for t, nm in ((x, "x"), (w_ohwi, "w")):
+        _need(t, FP8, nm)
+    _need(bias, torch.float32, "bias")
+    n, h, w, cin = x.shape
+    cout, k, k2, cin2 = w_ohwi.shape
+    if k != k2 or cin2 != cin or bias.numel() != cout:
+        raise ValueError("conv2d_fp8: inconsistent shapes")
+    ho = (h + 2 * pad - k) // stride + 1
+    wo = (w + 2 * pad - k) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=FP8, device=x.device)
+    if residual is not None:
+        _need(residual, FP8, "residual")
+        if residual.shape != y.shape:
+            raise ValueError("conv2d_fp8: residual shape mismatch")
+    bias_scaled = (bias / (sx * sw)).contiguous()
+    with torch.cuda.device(x.device):
+        rc = _lib.load_library().r50_op_conv2d_fp8(x.data_ptr(), n, h, w, cin, w_ohwi.data_ptr(), bias_scaled.data_ptr(),
+                                                   residual.data_ptr() if residual is not None else None, y.data_ptr(), cout, k, stride,
+                                                   pad, int(relu), float(sx * sw / sy), float(sr / sy), int(tile), _stream(x))
+    _lib.check(rc, None, "r50_op_conv2d_fp8")
+    return y
+
+
 def conv1x1_cat(x1: torch.Tensor, x2: torch.Tensor, stride2: int, wcat: torch.Tensor, bias: torch.Tensor, relu: bool = True,
                 tile: int = TILE_AUTO) -> torch.Tensor:
     """``act([W1 | W2] . [x1 ; x2 at stride2] + bias)``: conv3 + downsample + add + ReLU of a stage's first bottleneck as one 1x1

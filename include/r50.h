@@ -134,6 +134,16 @@ int r50_op_conv2d_f16(const void* x_nhwc_f16, int n, int h, int w, int cin, cons
                   const float* bias_f32, const void* residual_nhwc_f16, void* y_nhwc_f16,
                   int cout, int ksize, int stride, int pad, int relu, int tile, void* stream);
 
+/* fp8 convolution (BASELINE configs[4]: CDNA4 fp8 MFMA), kernel level.  OCP e4m3 activations, weights and output, fp32 accumulation on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales).  x (n,h,w,cin) fp8, w (cout,k,k,cin) fp8, residual / y (n,ho,wo,cout) fp8;
+ * with per-tensor scales sx, sw, sr, sy (real value = stored value x scale):
+ *   y = fp8( act( acc * oscale + residual * rscale ) ),  acc = bias_scaled + sum x*w,
+ *   bias_scaled = bias / (sx*sw) (device fp32), oscale = sx*sw/sy, rscale = sr/sy; conversion saturates at +-448.
+ * cin % 128 == 0, cout % 64 == 0 (128 / 256 for the wider tiles), k in {1,3}.  tile: 0 = auto or a role-specialised tile id (64|...). */
+int r50_op_conv2d_fp8(const void* x_nhwc_fp8, int n, int h, int w, int cin, const void* w_ohwi_fp8, const float* bias_scaled_f32,
+                      const void* residual_nhwc_fp8, void* y_nhwc_fp8, int cout, int ksize, int stride, int pad, int relu,
+                      float oscale, float rscale, int tile, void* stream);
+
 /* 1x1 conv over TWO K sources, the form the library runs conv3 + downsample + add + ReLU of a stage's first bottleneck in
  * (torchvision Bottleneck.forward: `out = conv3(out); identity = downsample(x); out += identity; relu`): y = act([W1 | W2] .
  * [x1 ; x2 sampled at stride2] + bias).  x1 (n,h,w,c1) at the output resolution, x2 (n,h2,w2,c2) with (h2-1)/stride2+1 == h;

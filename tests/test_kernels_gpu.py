@@ -333,3 +333,49 @@ def test_conv1x1_two_k_sources(lib_built, case, et):
         ops.conv1x1_cat(x1.to("cuda:0"), x2.to("cuda:0"), s2 + 1, wcat.to("cuda:0"), bias.to("cuda:0"))      # geometry mismatch
     with pytest.raises(Exception):
         ops.conv1x1_cat(x1.to("cuda:0"), x2.to("cuda:0"), s2, wcat.to("cuda:0"), bias.to("cuda:0"), tile=1)  # not a role-specialised tile
+
+
+FP8_CASES = [   # n, h, w, cin, cout, k, stride, pad, relu, residual, tile
+    (2, 8, 8, 128, 128, 1, 1, 0, True, False, 0),
+    (3, 5, 5, 256, 256, 1, 1, 0, True, True, 64 | 3),      # M = 75: ragged pixel tail, residual epilogue, 256x128 tile
+    (2, 8, 8, 256, 512, 1, 2, 0, False, False, 64 | 8),    # strided 1x1, no ReLU (negative outputs)
+    (3, 7, 7, 128, 128, 3, 1, 1, True, False, 64 | 1),     # 3x3: zero padding taps, K = 1152
+    (2, 9, 9, 128, 64, 3, 2, 1, True, False, 64 | 9),      # 3x3 stride 2, 64-cout tile
+    (1, 14, 14, 256, 256, 3, 1, 1, True, True, 64 | 4),    # layer3 conv2 shape with a residual, 4-consumer tile
+    (2, 7, 7, 1024, 256, 1, 1, 0, True, False, 64 | 8),    # K = 1024: 8 row-steps
+]
+
+
+@pytest.mark.parametrize("case", FP8_CASES, ids=lambda c: "n%d_%dx%d_c%d_o%d_k%d_s%d_p%d_r%d_res%d_t%d" % tuple(int(v) for v in c))
+def test_conv2d_fp8(lib_built, case):
+    """fp8 (e4m3) conv on the K = 128 scaled MFMA (BASELINE configs[4], kernel level) against a wide accumulation of the same
+    quantised operands, requantised with torch's round-to-nearest-even fp8 conversion."""
+    import torch.nn.functional as F
+    from implementation_phd_lab_vision_amd import ops
+    n, h, w, cin, cout, k, stride, pad, relu, has_res, tile = case
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    sx, sw, sr, sy = 0.05, 0.002, 0.04, 0.03
+    xq = (torch.randn(n, h, w, cin, generator=g) * 1.0 / sx * 0.5).clamp(-448, 448).to(ops.FP8)
+    wq = (torch.randn(cout, k, k, cin, generator=g) * (1.0 / (k * k * cin)) ** 0.5 / sw).clamp(-448, 448).to(ops.FP8)
+    bias = torch.randn(cout, generator=g) * 0.1
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    rq = (torch.randn(n, ho, wo, cout, generator=g) / sr * 0.5).clamp(-448, 448).to(ops.FP8) if has_res else None
+    y = ops.conv2d_fp8(xq.to("cuda:0"), sx, wq.to("cuda:0"), sw, bias.to("cuda:0"), sy, stride=stride, pad=pad, relu=bool(relu),
+                       residual=rq.to("cuda:0") if has_res else None, sr=sr, tile=tile)
+    assert y.dtype == ops.FP8 and tuple(y.shape) == (n, ho, wo, cout)
+    ref = F.conv2d(xq.double().permute(0, 3, 1, 2) * sx, wq.double().permute(0, 3, 1, 2) * sw, stride=stride, padding=pad)
+    ref = ref + bias.double().view(1, -1, 1, 1)
+    if has_res:
+        ref = ref + rq.double().permute(0, 3, 1, 2) * sr
+    if relu:
+        ref = F.relu(ref)
+    ref_q = (ref / sy).clamp(-448, 448).float().to(ops.FP8).float()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    diff = (got - ref_q).abs()
+    # one fp8 step at most (3 mantissa bits: spacing <= |v| / 8; 2^-9 in the subnormal range), and only where the fp32 sum sits on a tie
+    assert not (diff > ref_q.abs() * 0.126 + 2.0 ** -9 + 1e-7).any(), float(diff.max())
+    assert float((diff > 0).float().mean()) < 0.02, float((diff > 0).float().mean())
+    assert float(got.abs().max()) > 1.0                       # a real signal, not all zeros
+    with pytest.raises(Exception):
+        ops.conv2d_fp8(xq.to("cuda:0")[..., :64].contiguous(), sx, wq.to("cuda:0")[..., :64].contiguous(), sw, bias.to("cuda:0"), sy)   # cin % 128
