@@ -85,8 +85,9 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=BATCH, help="frames per GPU per step (headline config: 256)")
     ap.add_argument("--micro-batch", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="internal streams the batch is split over (0 = library default)")
-    ap.add_argument("--precision", choices=["bf16", "fp16", "bf16w2", "fp32x"], default="bf16",
-                    help="bf16 = headline path; fp32x = fp32-class accuracy mode (bf16 head/tail pairs, 3 products per conv)")
+    ap.add_argument("--precision", choices=["bf16", "fp16", "bf16w2", "fp32x", "fp8"], default="bf16",
+                    help="bf16 = headline path; fp32x = fp32-class accuracy mode (bf16 head/tail pairs, 3 products per conv); "
+                         "fp8 = BASELINE configs[4] (layer2-4 on the fp8 MFMA; a throughput mode, not the headline)")
     ap.add_argument("--from-host", action="store_true",
                     help="PCIe-inclusive variant (never the headline value): frames start in pinned host memory every step; the "
                          "copy of step k+1 runs on a side stream while step k computes")
@@ -274,9 +275,10 @@ def main() -> None:
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "fp16", "bf16w2": "bf16 (weights as bf16 head+tail pairs)",
-                                            "fp32x": "bf16x3 (fp32-class)"}[args.precision], "data": "synthetic",
-            "config": {"workload": f"ResNet-50[:-1] bf16 forward, batch {args.batch} x 224x224x3 fp32 NCHW frames per GPU "
-                                   f"(BASELINE configs[1]), seeded synthetic weights, (N,2048) fp32 features"
+                                            "fp32x": "bf16x3 (fp32-class)", "fp8": "fp8 e4m3 (layer2-4; stem + layer1 bf16)"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": f"ResNet-50[:-1] {args.precision} forward, batch {args.batch} x 224x224x3 fp32 NCHW frames per GPU "
+                                   f"(BASELINE configs[{4 if args.precision == 'fp8' else 1}]), seeded synthetic weights, (N,2048) fp32 features"
                                    + (", RCCL gather to rank 0" if world > 1 else ""),
                        "batch_per_gpu": args.batch, "micro_batch": args.micro_batch,
                        "input": args.input + (" from pinned host memory every step (PCIe-inclusive, H2D overlapped)" if args.from_host else ""),

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "r50_profile_count": (C.c_int, [C.c_void_p]),
     "r50_profile_entry": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "r50_set_fp8_scales": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "r50_get_packed": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "r50_op_conv2d": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

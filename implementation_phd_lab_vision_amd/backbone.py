@@ -26,8 +26,22 @@ PREC_BF16 = 1     # bf16 operands, fp32 accumulation: the fast path (the referen
 PREC_FP32X = 2    # fp32-class accuracy on the bf16 matrix cores (bf16 head/tail pairs, 3 products per conv)
 PREC_BF16W2 = 3   # bf16 activations, weights as bf16 head/tail pairs (2 products per conv): within 1e-3 of the fp32 reference
 PREC_FP16 = 4     # IEEE half operands / activations, same kernels and speed as bf16; 3e-4 from the fp32 reference
-_PRECISIONS = {"bf16": PREC_BF16, "fp32x": PREC_FP32X, "bf16w2": PREC_BF16W2, "fp16": PREC_FP16, PREC_BF16: PREC_BF16,
-               PREC_FP32X: PREC_FP32X, PREC_BF16W2: PREC_BF16W2, PREC_FP16: PREC_FP16}
+PREC_FP8 = 5      # BASELINE configs[4]: layer2-4 on e4m3 tensors and the K = 128 fp8 MFMA (stem + layer1 stay bf16); a throughput mode
+_PRECISIONS = {"bf16": PREC_BF16, "fp32x": PREC_FP32X, "bf16w2": PREC_BF16W2, "fp16": PREC_FP16, "fp8": PREC_FP8, PREC_BF16: PREC_BF16,
+               PREC_FP32X: PREC_FP32X, PREC_BF16W2: PREC_BF16W2, PREC_FP16: PREC_FP16, PREC_FP8: PREC_FP8}
+FP8_NUM_SCALES = 43
+FP8_MARGIN = 1.25     # scale = margin * absmax / 448: head-room for frames whose activations exceed the calibration batch's
+
+
+def fp8_tap_names():
+    """The fp8 part's tensors in execution order (r50_set_fp8_scales): layer1's output, then per bottleneck of layer2-4
+    conv1 output, conv2 output, [downsample output], block output."""
+    names = ["layer1.2"]
+    for si, blocks in ((2, 4), (3, 6), (4, 3)):
+        for b in range(blocks):
+            p = f"layer{si}.{b}"
+            names += [p + ".t1", p + ".t2"] + ([p + ".ds"] if b == 0 else []) + [p]
+    return names
 
 
 class ResNet50Backbone:
@@ -46,7 +60,7 @@ class ResNet50Backbone:
         self._max_batch = int(max_batch)
         self._micro_batch = int(micro_batch)
         if precision not in _PRECISIONS:
-            raise ValueError(f"precision must be 'bf16', 'fp16', 'bf16w2' or 'fp32x', got {precision!r}")
+            raise ValueError(f"precision must be 'bf16', 'fp16', 'bf16w2', 'fp32x' or 'fp8', got {precision!r}")
         self._precision = _PRECISIONS[precision]
         self._handle: Optional[int] = None
         self._device: Optional[torch.device] = None
@@ -79,7 +93,36 @@ class ResNet50Backbone:
         _lib.check(lib.r50_load_weights(self._handle, descs, len(named)), self._handle, "r50_load_weights")
         if self._micro_batch:
             self.set_option("micro_batch", self._micro_batch)
+        if self._precision == PREC_FP8:
+            self.calibrate_fp8()
         return self
+
+    # ---- fp8 mode: activation scales ----------------------------------------------------------
+    def set_fp8_scales(self, scales) -> None:
+        """Per-tensor activation scales of the fp8 part in ``fp8_tap_names()`` order (real value = stored e4m3 value x scale)."""
+        vals = [float(v) for v in scales]
+        if len(vals) != FP8_NUM_SCALES:
+            raise ValueError(f"expected {FP8_NUM_SCALES} scales, got {len(vals)}")
+        arr = (C.c_float * FP8_NUM_SCALES)(*vals)
+        _lib.check(_lib.load_library().r50_set_fp8_scales(self._handle, arr, FP8_NUM_SCALES), self._handle, "r50_set_fp8_scales")
+        self.fp8_scales = vals
+
+    def calibrate_fp8(self, frames: Optional[torch.Tensor] = None, margin: float = FP8_MARGIN):
+        """Choose the activation scales from the largest magnitude each tensor takes in the bf16 network (same weights) on a
+        calibration batch: ``frames`` (N,3,224,224) fp32 on the device, or 8 seeded synthetic frames.  Returns the scales."""
+        from .weights import synthetic_frames
+        if frames is None:
+            frames = synthetic_frames(8, seed=4321).to(self._device)
+        ref = ResNet50Backbone(state_dict=self._sd, max_batch=int(frames.shape[0]), precision="bf16").to(self._device).eval()
+        try:
+            scales = []
+            for name in fp8_tap_names():
+                amax = float(ref.layer(frames, name).float().abs().max())
+                scales.append(margin * max(amax, 1e-6) / 448.0)
+        finally:
+            ref.close()
+        self.set_fp8_scales(scales)
+        return scales
 
     def cuda(self, device=None) -> "ResNet50Backbone":
         return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))

@@ -2068,6 +2068,42 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const __bf16* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp8 network mode (R50_PREC_FP8): hand-over of the 16-bit layer1 output to the fp8 stack, and the final pool on fp8 input.
+// ------------------------------------------------------------------------------------------------
+template <int ET>
+__global__ __launch_bounds__(256) void quant_to_fp8_kernel(const unsigned short* __restrict__ src, unsigned* __restrict__ dst, long long n4,
+                                                           float inv_scale) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(src + 4 * i);
+        dst[i] = pack4_fp8(unpack_lo_e<ET>(v[0]) * inv_scale, unpack_hi_e<ET>(v[0]) * inv_scale, unpack_lo_e<ET>(v[1]) * inv_scale,
+                           unpack_hi_e<ET>(v[1]) * inv_scale);
+    }
+}
+
+// (N, HW, C) fp8 -> (N, C) fp32: rows summed in order in fp32, times scale / HW.  One thread per (n, 8 channels).
+__global__ __launch_bounds__(256) void avgpool_fp8_kernel(const unsigned char* __restrict__ x, float* __restrict__ y, int N, int HW, int C,
+                                                          float scale_over_hw) {
+    const int cg = C >> 3;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * cg) return;
+    const int g = idx % cg, n = idx / cg;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    const unsigned char* p = x + (size_t)n * HW * C + g * 8;
+    for (int r = 0; r < HW; ++r) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(p + (size_t)r * C);
+        s[0] += __builtin_amdgcn_cvt_f32_fp8((int)v[0], 0); s[1] += __builtin_amdgcn_cvt_f32_fp8((int)v[0], 1);
+        s[2] += __builtin_amdgcn_cvt_f32_fp8((int)v[0], 2); s[3] += __builtin_amdgcn_cvt_f32_fp8((int)v[0], 3);
+        s[4] += __builtin_amdgcn_cvt_f32_fp8((int)v[1], 0); s[5] += __builtin_amdgcn_cvt_f32_fp8((int)v[1], 1);
+        s[6] += __builtin_amdgcn_cvt_f32_fp8((int)v[1], 2); s[7] += __builtin_amdgcn_cvt_f32_fp8((int)v[1], 3);
+    }
+    float* o = y + (size_t)n * C + g * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = s[e] * scale_over_hw;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Global average pool: (N, HW, C) bf16 -> (N, C) fp32.  One thread per (n, 8 channels); the HW rows
 // are summed in order in fp32 and multiplied by 1/HW.
 // ------------------------------------------------------------------------------------------------

@@ -37,6 +37,11 @@ struct ConvLayer {
     int cin, cout, ks, stride, pad;
     __bf16* w = nullptr;    // device, (cout, ks, ks, cin)
     float* bias = nullptr;  // device
+    // fp8 mode, layer2-4: w holds e4m3 bytes with real value = byte value x wscale; bias_scaled = bias / (sx * wscale) once the
+    // activation scales are known (r50_set_fp8_scales)
+    float wscale = 1.0f;
+    float* bias_scaled = nullptr;
+    std::vector<float> bias_host;
 };
 
 }  // namespace
@@ -53,6 +58,7 @@ struct r50_handle {
     hipEvent_t ev_ds_fork = nullptr, ev_ds_join = nullptr;
     int fused_stem = 1;                 // bf16 mode: conv1+bn1+relu+maxpool in one kernel
     int fuse_stem_c1 = 1;               // strip stem kernel also computes layer1.0.conv1
+    std::vector<float> fp8_scales;      // R50_PREC_FP8: activation scales, execution order (r50_set_fp8_scales)
     int fuse_ds_cat = 1;                // layer2.0 / 3.0 / 4.0: conv3 and the downsample conv as one GEMM over K = [t2 | x at stride 2]
     __bf16* cat_w[4] = {nullptr, nullptr, nullptr, nullptr};      // per stage: (cout, cmid + cin) = [W3 | Wd], device
     float* cat_bias[4] = {nullptr, nullptr, nullptr, nullptr};    // b3 + bd (fp32)
@@ -98,6 +104,7 @@ inline uint16_t f32_to_bf16_rne(float f) {
 }
 
 constexpr int kStages[4][3] = {{64, 3, 1}, {128, 4, 2}, {256, 6, 2}, {512, 3, 2}};
+constexpr size_t kFp8FirstConv = 11;     // convs[1..10] = layer1 (4 + 3 + 3); fp8 mode quantises from layer2.0.conv1 on
 constexpr float kBnEps = 1e-5f;
 
 std::vector<ConvLayer> make_specs() {
@@ -157,6 +164,39 @@ void pack_ohwi_f16(const float* wf, int cout, int cin, int ks, std::vector<uint1
         for (int c = 0; c < cin; ++c)
             for (int t = 0; t < ks * ks; ++t)
                 out[((size_t)o * ks * ks + t) * cin + c] = f32_to_f16_rne(wf[((size_t)o * cin + c) * ks * ks + t]);
+}
+
+// fp32 -> OCP e4m3 (fn: no infinities, S.1111.111 = NaN), round to nearest even, saturating at +-448
+inline uint8_t f32_to_e4m3(float v) {
+    const uint8_t sign = std::signbit(v) ? 0x80 : 0x00;
+    float a = std::fabs(v);
+    if (!(a == a)) return (uint8_t)(sign | 0x7f);
+    if (a >= 448.0f) return (uint8_t)(sign | 0x7e);
+    if (a < 0.015625f) {                                   // below 2^-6: subnormals, step 2^-9
+        const int q = (int)std::nearbyint(a * 512.0f);     // 0 .. 8 (8 = the smallest normal)
+        return (uint8_t)(sign | q);
+    }
+    int e;
+    const float m = std::frexp(a, &e);                     // a = m * 2^e, m in [0.5, 1)
+    int q = (int)std::nearbyint((m * 2.0f - 1.0f) * 8.0f); // mantissa steps of the binade [2^(e-1), 2^e)
+    int ex = e - 1;
+    if (q == 8) { q = 0; ++ex; }
+    if (ex > 8 || (ex == 8 && q > 6)) return (uint8_t)(sign | 0x7e);
+    return (uint8_t)(sign | ((ex + 7) << 3) | q);
+}
+// (cout, cin, k, k) fp32 -> (cout, k, k, cin) e4m3 bytes with one scale for the tensor (absmax / 448); returns the scale
+float pack_ohwi_fp8(const float* wf, int cout, int cin, int ks, std::vector<uint16_t>& out) {
+    const size_t total = (size_t)cout * ks * ks * cin;
+    float amax = 0.f;
+    for (size_t i = 0; i < total; ++i) amax = std::fmax(amax, std::fabs(wf[i]));
+    const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+    out.assign((total + 1) / 2, 0);
+    uint8_t* o = reinterpret_cast<uint8_t*>(out.data());
+    for (int oc = 0; oc < cout; ++oc)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < ks * ks; ++t)
+                o[((size_t)oc * ks * ks + t) * cin + c] = f32_to_e4m3(wf[((size_t)oc * cin + c) * ks * ks + t] / scale);
+    return scale;
 }
 
 void pack_ohwi_bf16(const float* wf, int cout, int cin, int ks, std::vector<uint16_t>& out) {
@@ -748,6 +788,78 @@ hipError_t launch_avgpool(const void* x, float* y, int n, int hw, int c, hipStre
     return hipGetLastError();
 }
 
+// ---- R50_PREC_FP8: layer2-4 on e4m3 tensors ----------------------------------------------------------------------------
+int run_conv_fp8(r50_handle* h, const ConvLayer& L, const void* x, int n, int hh, int ww, const void* res, void* y, int relu, float sx,
+                 float sr, float sy, hipStream_t s, int* ho, int* wo) {
+    ConvArgs a;
+    int rc = fill_conv_args(a, x, n, hh, ww, L.cin / 2, L.w, L.bias_scaled, res, y, L.cout, L.ks, L.stride, L.pad, relu);
+    if (rc) return fail(h, rc, "fp8 conv args invalid for " + L.conv_key);
+    a.y_bytes = (unsigned)((long long)a.M * L.cout);
+    a.et = 2; a.oscale = sx * L.wscale / sy; a.rscale = sr / sy;
+    EvRec r{};
+    const double flops = 2.0 * a.M * (double)a.Cout * L.ks * L.ks * L.cin;
+    const double bytes = (double)n * hh * ww * L.cin + (double)a.M * a.Cout * (res ? 2 : 1) + (double)a.Cout * L.ks * L.ks * L.cin;
+    prof_begin(h, s, r, PC_IGEMM, flops, bytes, (int)(&L - &h->convs[0]));
+    hipError_t e = launch_igemm_fp8(a, 0, s);
+    prof_end(h, s, r);
+    if (e != hipSuccess) return fail(h, R50_ERR_HIP, "fp8 igemm launch (" + L.conv_key + "): " + hipGetErrorString(e));
+    *ho = a.Ho; *wo = a.Wo;
+    return R50_OK;
+}
+
+// buf[cur] holds layer1's output (n,56,56,256) as 16-bit elements: quantise it, run layer2-4 in fp8, pool.
+int run_fp8_part(r50_handle* h, __bf16* const* buf, int cur, int n, float* out, hipStream_t s) {
+    if ((int)h->fp8_scales.size() != R50_FP8_NUM_SCALES)
+        return fail(h, R50_ERR_STATE, "fp8 mode: call r50_set_fp8_scales (activation scales) before the first forward");
+    const float* sc = h->fp8_scales.data();
+    int k = 0;
+    float s_in = sc[k++];
+    EvRec r{};
+    int nxt = (cur + 1) % 5;
+    {
+        const long long n4 = (long long)n * 56 * 56 * 256 / 4;
+        prof_begin(h, s, r, PC_MAXPOOL, 0, (double)n4 * 12);
+        hipLaunchKernelGGL(quant_to_fp8_kernel<0>, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 256 * 64)), dim3(256), 0, s,
+                           (const unsigned short*)buf[cur], (unsigned*)buf[nxt], n4, 1.0f / s_in);
+        prof_end(h, s, r);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("quant_to_fp8: ") + hipGetErrorString(e));
+        cur = nxt;
+    }
+    int hh = 56, ww = 56;
+    size_t li = kFp8FirstConv;
+    for (int si = 1; si < 4; ++si)
+        for (int b = 0; b < kStages[si][1]; ++b) {
+            int fr[4], nf = 0;
+            for (int i = 0; i < 5; ++i)
+                if (i != cur) fr[nf++] = i;
+            const ConvLayer &c1 = h->convs[li], &c2 = h->convs[li + 1], &c3 = h->convs[li + 2];
+            const float s_t1 = sc[k++], s_t2 = sc[k++];
+            int h1, w1, h2, w2, h3, w3, rc;
+            if ((rc = run_conv_fp8(h, c1, buf[cur], n, hh, ww, nullptr, buf[fr[0]], 1, s_in, 1.f, s_t1, s, &h1, &w1))) return rc;
+            if ((rc = run_conv_fp8(h, c2, buf[fr[0]], n, h1, w1, nullptr, buf[fr[1]], 1, s_t1, 1.f, s_t2, s, &h2, &w2))) return rc;
+            const void* idn = buf[cur];
+            float s_idn = s_in;
+            if (b == 0) {
+                const float s_ds = sc[k++];
+                int hd, wd;
+                if ((rc = run_conv_fp8(h, h->convs[li + 3], buf[cur], n, hh, ww, nullptr, buf[fr[2]], 0, s_in, 1.f, s_ds, s, &hd, &wd))) return rc;
+                idn = buf[fr[2]]; s_idn = s_ds;
+            }
+            const float s_out = sc[k++];
+            if ((rc = run_conv_fp8(h, c3, buf[fr[1]], n, h2, w2, idn, buf[fr[3]], 1, s_t2, s_idn, s_out, s, &h3, &w3))) return rc;
+            cur = fr[3]; hh = h3; ww = w3; s_in = s_out;
+            li += (b == 0) ? 4 : 3;
+        }
+    prof_begin(h, s, r, PC_AVGPOOL, 0, (double)n * (hh * ww * 2048.0 + 2048.0 * 4));
+    hipLaunchKernelGGL(avgpool_fp8_kernel, dim3((n * 256 + 255) / 256), dim3(256), 0, s, (const unsigned char*)buf[cur], out, n, hh * ww, 2048,
+                       s_in / (float)(hh * ww));
+    prof_end(h, s, r);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, R50_ERR_HIP, std::string("avgpool_fp8: ") + hipGetErrorString(e));
+    return R50_OK;
+}
+
 // Runs `n` frames (n <= max_batch) through the stack.  If `tap` is non-null, stops once the named
 // activation is available and reports it through tap_ptr / dims.
 template <typename TIN>
@@ -781,7 +893,7 @@ int run_stack(r50_handle* h, const TIN* x, int n, float* out, hipStream_t s, con
         // conv1 + bn1 + relu + maxpool in one kernel: frame in, (n,56,56,64) out
         // ... and, in the strip version, layer1.0.conv1 (1x1, 64 -> 64) of the pooled rows into buf[2] while they are still in LDS
         const ConvLayer& l1c1 = h->convs[1];
-        stem_c1 = h->fuse_stem_c1 && stem_strip_enabled() && (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16) &&
+        stem_c1 = h->fuse_stem_c1 && stem_strip_enabled() && (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16 || h->precision == R50_PREC_FP8) &&
                   h->tile_override == 0 && l1c1.ks == 1 && l1c1.stride == 1 && l1c1.cin == 64 && l1c1.cout == 64;
         prof_begin(h, s, r, PC_STEM_CONV, 2.0 * n * 112 * 112 * 64 * 147.0 + (stem_c1 ? 2.0 * n * 56 * 56 * 64 * 64 : 0.0),
                    (double)n * (3.0 * 224 * 224 * 4 + 56.0 * 56 * 64 * 2 * (stem_c1 ? 2 : 1)));
@@ -816,6 +928,10 @@ after_pool:
     size_t li = 1;
     for (int si = 0; si < 4; ++si) {
         const int blocks = kStages[si][1];
+        if (si == 1 && h->precision == R50_PREC_FP8) {
+            if (tap) return fail(h, R50_ERR_INVALID, "fp8 mode: activations beyond layer1 are e4m3 tensors, taps stop at layer1.2");
+            return run_fp8_part(h, buf, cur, n, out, s);
+        }
         for (int b = 0; b < blocks; ++b) {
             int fr[4], nf = 0;
             if (pre_t1 >= 0) fr[nf++] = pre_t1;          // conv1 of this block was computed by the previous block's fused tail
@@ -835,7 +951,8 @@ after_pool:
             // block the identity (downsample conv of the block input) is computed inside that kernel as well
             const size_t li_next = li + ((b == 0) ? 4 : 3);
             const ConvLayer* nx = (li_next < h->convs.size()) ? &h->convs[li_next] : nullptr;
-            const bool fuse_ok = !split && (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16) && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
+            const bool nx_is_fp8 = (h->precision == R50_PREC_FP8 && li_next >= kFp8FirstConv);     // the next conv1's weights are e4m3 bytes
+            const bool fuse_ok = !split && !nx_is_fp8 && (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16 || h->precision == R50_PREC_FP8) && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
                                  nx->ks == 1 && nx->stride == 1;
             const bool fuse2 = fuse_ok && c3.cin == 128 && c3.cout == 512 && nx->cin == 512 && nx->cout == 128;   // layer2 shapes
             const ConvLayer* cdp = (b == 0) ? &h->convs[li + 3] : nullptr;
@@ -926,7 +1043,8 @@ void free_all(r50_handle* h) {
     for (auto& L : h->convs) {
         if (L.w) (void)hipFree(L.w);
         if (L.bias) (void)hipFree(L.bias);
-        L.w = nullptr; L.bias = nullptr;
+        if (L.bias_scaled) (void)hipFree(L.bias_scaled);
+        L.w = nullptr; L.bias = nullptr; L.bias_scaled = nullptr;
     }
     for (int i = 0; i < 4; ++i) {
         if (h->cat_w[i]) (void)hipFree(h->cat_w[i]);
@@ -1006,7 +1124,8 @@ const char* r50_last_error(r50_handle* h) { return h ? h->err.c_str() : g_err.c_
 int r50_create(r50_handle** out, int device_id, int precision, int max_batch) {
     if (!out) return fail(nullptr, R50_ERR_INVALID, "r50_create: out is null");
     *out = nullptr;
-    if (precision != R50_PREC_BF16 && precision != R50_PREC_FP32X && precision != R50_PREC_BF16W2 && precision != R50_PREC_FP16)
+    if (precision != R50_PREC_BF16 && precision != R50_PREC_FP32X && precision != R50_PREC_BF16W2 && precision != R50_PREC_FP16 &&
+        precision != R50_PREC_FP8)
         return fail(nullptr, R50_ERR_INVALID, "r50_create: unsupported precision");
     const int cmul = (precision == R50_PREC_FP32X) ? 2 : 1;
     if (max_batch < 1 || max_batch > 1024) return fail(nullptr, R50_ERR_INVALID, "r50_create: max_batch must be in [1,1024]");
@@ -1093,6 +1212,7 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
         if ((rc = need(L.bn_key + ".running_mean", L.cout, &m))) return rc;
         if ((rc = need(L.bn_key + ".running_var", L.cout, &v))) return rc;
         fold_bn(w, g, b, m, v, L.cout, per_out, wf, bf);
+        L.bias_host = bf;
         if (!L.bias) HIP_TRY(h, hipMalloc((void**)&L.bias, L.cout * sizeof(float)));
         HIP_TRY(h, hipMemcpy(L.bias, bf.data(), L.cout * sizeof(float), hipMemcpyHostToDevice));
         const bool split = (h->precision == R50_PREC_FP32X);
@@ -1107,6 +1227,7 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
             if (split) pack_ohwi_split(wf.data(), L.cout, L.cin, L.ks, pk);
             else if (h->precision == R50_PREC_BF16W2) pack_ohwi_w2(wf.data(), L.cout, L.cin, L.ks, pk);
             else if (h->precision == R50_PREC_FP16) pack_ohwi_f16(wf.data(), L.cout, L.cin, L.ks, pk);
+            else if (h->precision == R50_PREC_FP8 && i >= kFp8FirstConv) L.wscale = pack_ohwi_fp8(wf.data(), L.cout, L.cin, L.ks, pk);
             else pack_ohwi_bf16(wf.data(), L.cout, L.cin, L.ks, pk);
             if (!L.w) HIP_TRY(h, hipMalloc((void**)&L.w, pk.size() * 2));
             HIP_TRY(h, hipMemcpy(L.w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
@@ -1137,6 +1258,42 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
         }
     }
     h->loaded = true;
+    h->fp8_scales.clear();              // new weights: bias_scaled must be rebuilt
+    return R50_OK;
+}
+
+int r50_set_fp8_scales(r50_handle* h, const float* scales, int n) {
+    if (!h || !scales) return fail(h, R50_ERR_INVALID, "r50_set_fp8_scales: null argument");
+    if (h->precision != R50_PREC_FP8) return fail(h, R50_ERR_STATE, "r50_set_fp8_scales: handle is not in R50_PREC_FP8 mode");
+    if (!h->loaded) return fail(h, R50_ERR_STATE, "r50_set_fp8_scales: weights not loaded");
+    if (n != R50_FP8_NUM_SCALES) return fail(h, R50_ERR_INVALID, "r50_set_fp8_scales: expected R50_FP8_NUM_SCALES values");
+    for (int i = 0; i < n; ++i)
+        if (!(scales[i] > 0.f) || !std::isfinite(scales[i])) return fail(h, R50_ERR_INVALID, "r50_set_fp8_scales: scales must be positive and finite");
+    HIP_TRY(h, hipSetDevice(h->device));
+    // input scale of every fp8 conv, walking the blocks in execution order (same walk as run_fp8_part)
+    size_t li = kFp8FirstConv;
+    int k = 0;
+    float s_in = scales[k++];
+    std::vector<float> tmp;
+    auto set_bias = [&](ConvLayer& L, float sx) -> int {
+        tmp.resize(L.cout);
+        for (int o = 0; o < L.cout; ++o) tmp[o] = L.bias_host[o] / (sx * L.wscale);
+        if (!L.bias_scaled) HIP_TRY(h, hipMalloc((void**)&L.bias_scaled, L.cout * sizeof(float)));
+        HIP_TRY(h, hipMemcpy(L.bias_scaled, tmp.data(), L.cout * sizeof(float), hipMemcpyHostToDevice));
+        return R50_OK;
+    };
+    for (int si = 1; si < 4; ++si)
+        for (int b = 0; b < kStages[si][1]; ++b) {
+            const float s_t1 = scales[k++], s_t2 = scales[k++];
+            int rc;
+            if ((rc = set_bias(h->convs[li], s_in))) return rc;
+            if ((rc = set_bias(h->convs[li + 1], s_t1))) return rc;
+            if ((rc = set_bias(h->convs[li + 2], s_t2))) return rc;
+            if (b == 0) { ++k; if ((rc = set_bias(h->convs[li + 3], s_in))) return rc; }
+            s_in = scales[k++];
+            li += (b == 0) ? 4 : 3;
+        }
+    h->fp8_scales.assign(scales, scales + n);
     return R50_OK;
 }
 
@@ -1256,6 +1413,7 @@ int r50_get_packed(r50_handle* h, const char* conv_key, int what, void* dst_host
         int64_t bytes;
         if (what == 1) { src = L.bias; bytes = (int64_t)L.cout * 4; }
         else if (i == 0) { src = h->stem_w; bytes = STEM_W_BYTES; }
+        else if (h->precision == R50_PREC_FP8 && i >= kFp8FirstConv) { src = L.w; bytes = (int64_t)L.cout * L.ks * L.ks * L.cin; }
         else { src = L.w; bytes = (int64_t)L.cout * L.ks * L.ks * L.cin * 2 * (h->precision == R50_PREC_FP32X ? 3 : h->precision == R50_PREC_BF16W2 ? 2 : 1); }
         *bytes_out = bytes;
         if (bytes > capacity_bytes) return fail(h, R50_ERR_INVALID, "r50_get_packed: buffer too small");

@@ -48,9 +48,13 @@ typedef enum r50_precision {
                                products per conv, one fp32 accumulator, activation traffic as in bf16 mode.  The bf16
                                error of this network is dominated by WEIGHT rounding, so this is enough to bring the
                                features within 1e-3 (rel-L2) of the fp32 reference at about half the fp32x cost */
-    R50_PREC_FP16 = 4       /* IEEE half operands and activations, fp32 MFMA accumulation: the bf16 path with the other
+    R50_PREC_FP16 = 4,      /* IEEE half operands and activations, fp32 MFMA accumulation: the bf16 path with the other
                                16-bit format (same kernels, same traffic, same speed; conversions saturate at 65504).
                                11 significand bits instead of 8 put the features 3e-4 from the fp32 reference */
+    R50_PREC_FP8 = 5        /* BASELINE configs[4]: stem + layer1 as in bf16 mode (their 64-channel convs cannot fill a
+                               128-byte fp8 K row), layer2-4 with OCP e4m3 weights and activations on the K = 128 scaled fp8
+                               MFMA (per-tensor scales, fp32 accumulation).  Needs r50_set_fp8_scales before the first
+                               forward.  A throughput mode: the features are ~1e-1 (rel-L2) from the fp32 reference */
 } r50_precision;
 
 /* One host tensor handed to r50_load_weights: torchvision state-dict key + fp32 data. */
@@ -116,6 +120,12 @@ int r50_profile_entry(r50_handle* h, int i, const char** name, int64_t* launches
 int r50_get_packed(r50_handle* h, const char* conv_key, int what, void* dst_host, int64_t capacity_bytes,
                    int64_t* bytes_out);
 
+/* R50_PREC_FP8 only: per-tensor activation scales (real value = stored fp8 value x scale) of the fp8 part, in execution order:
+ * scales[0] = layer1's output (the bf16 -> fp8 hand-over), then per bottleneck of layer2, layer3, layer4: conv1 output, conv2 output,
+ * [downsample output, first block of a layer only], block output: R50_FP8_NUM_SCALES values (calibrated on the host, e.g. 1.25 x
+ * absmax / 448 of the bf16 network's tensors: backbone.py).  Weight scales are chosen by r50_load_weights (absmax / 448 per conv). */
+#define R50_FP8_NUM_SCALES 43
+int r50_set_fp8_scales(r50_handle* h, const float* scales, int n);
 const char* r50_last_error(r50_handle* h);   /* h may be NULL: last error of r50_create / r50_op_* */
 void r50_destroy(r50_handle* h);             /* replaces: del backbone */
 const char* r50_version(void);

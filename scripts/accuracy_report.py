@@ -22,3 +22,10 @@ for prec in ("bf16", "fp16", "bf16w2", "fp32x"):
     print(f"device {prec:6s} vs fp64 ref : max per-frame rel-L2 %.3e   max-abs %.3e   (vs bf16-emu oracle %.3e)" %
           (float(O.per_row_rel_l2(f, f64).max()), float((f.double() - f64).abs().max()), float(O.per_row_rel_l2(f, emu).max())))
     bb.close()
+bb = ResNet50Backbone(state_dict=sd, max_batch=8, precision="fp8").to("cuda:0").eval()       # calibrated on 8 other synthetic frames
+f = bb(x.to("cuda:0")).flatten(1).cpu()
+emu8 = O.forward_fp8_emulated(sd, x, bb.fp8_scales)
+print("oracle fp8-emu vs fp64   : max per-frame rel-L2 %.3e" % float(O.per_row_rel_l2(emu8, f64).max()))
+print("device fp8    vs fp64 ref : max per-frame rel-L2 %.3e   (vs fp8-emu oracle %.3e)" %
+      (float(O.per_row_rel_l2(f, f64).max()), float(O.per_row_rel_l2(f, emu8).max())))
+bb.close()
