@@ -72,3 +72,18 @@ def test_reference_view_matches_fp64(sd):
     a = O.forward_reference(sd, x).flatten(1)
     b = O.forward_reference(sd, x, dtype=torch.float64).flatten(1)
     assert tuple(a.shape) == (2, 2048) and float(O.per_row_rel_l2(a, b).max()) < 1e-5
+
+
+def test_fp8_emulation_pieces():
+    """The fp8 mode's oracle (R50_PREC_FP8): e4m3 rounding, weight scales, the tensor order shared with the device."""
+    from implementation_phd_lab_vision_amd.backbone import FP8_NUM_SCALES, fp8_tap_names
+    names = fp8_tap_names()
+    assert len(names) == FP8_NUM_SCALES == 43 and names[0] == "layer1.2" and names[1:5] == ["layer2.0.t1", "layer2.0.t2", "layer2.0.ds", "layer2.0"]
+    assert names[-1] == "layer4.2" and sum(n.endswith(".ds") for n in names) == 3
+    v = torch.tensor([0.0, 1.0, 1.0625, 1.1875, 448.0, 500.0, -1e9, 2.0 ** -9, 2.0 ** -10, 3 * 2.0 ** -10, 0.3])
+    want = torch.tensor([0.0, 1.0, 1.0, 1.25, 448.0, 448.0, -448.0, 2.0 ** -9, 0.0, 2.0 ** -8, 0.3125])     # ties to even, saturation
+    assert torch.equal(O.fp8_round(v), want)
+    w = torch.tensor([[0.5, -2.0], [1.0, 0.25]])
+    wq, s = O.fp8_weight(w)
+    assert s == pytest.approx(2.0 / 448) and torch.equal(wq, torch.tensor([[112.0, -448.0], [224.0, 56.0]]))
+    assert O.fp8_weight(torch.zeros(3))[1] == 1.0
