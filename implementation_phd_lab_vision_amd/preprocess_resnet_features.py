@@ -15,7 +15,7 @@ The clip dataset is the reference's own ``Human36MPreprocessedClips`` (src/datas
 ``$H36M_REFERENCE_SRC`` or ``sys.path`` — the frame producer is upstream of this path.  Extra,
 optional flags (defaults keep the reference behaviour): ``--weights`` (local torchvision checkpoint;
 otherwise seeded synthetic weights — nothing is downloaded), ``--synthetic-clips N`` (run without
-H36M data), ``--precision {bf16,fp32x}``, ``--micro-batch``, ``--max-batch``.
+H36M data), ``--precision {bf16,fp16,bf16w2,fp32x,fp8}``, ``--micro-batch``, ``--max-batch``.
 """
 from __future__ import annotations
 
@@ -55,7 +55,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--weights", type=str, default=None, help="Local torchvision resnet50-*.pth (default: seeded synthetic)")
     p.add_argument("--weights-seed", type=int, default=0)
     p.add_argument("--synthetic-clips", type=int, default=0, help="Use N synthetic clips instead of reading --root")
-    p.add_argument("--precision", choices=["bf16", "fp16", "bf16w2", "fp32x"], default="bf16",
+    p.add_argument("--precision", choices=["bf16", "fp16", "bf16w2", "fp32x", "fp8"], default="bf16",
                    help="bf16 = the reference's CUDA autocast dtype (fast); fp32x = fp32-class accuracy (its CPU numerics), ~2.7x slower")
     p.add_argument("--micro-batch", type=int, default=0, help="Frames per pass through the layer stack (0 = auto)")
     p.add_argument("--max-batch", type=int, default=256, help="Frames per backbone call chunk (workspace size)")
