@@ -390,7 +390,7 @@ long long tiles_of(const ConvArgs& a, int tile) {
     if (tile & kWsBit) {
         switch (tile & (kPersistBit - 1)) {
             case 1: bc = 128; bp = 128; break;  case 3: bc = 256; bp = 128; break;  case 4: case 8: bc = 128; bp = 224; break;
-            case 9: bc = 64; bp = 224; break;   default: return 0;
+            case 9: bc = 64; bp = 224; break;   case 10: bc = 128; bp = 208; break;   default: return 0;
         }
     } else {
         switch (tile & (kPersistBit - 1)) {
@@ -446,6 +446,9 @@ hipError_t launch_igemm_et(const ConvArgs& a, int tile, hipStream_t s, bool spli
             case 4: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_ws_t<ET, 128, 224, 2, 2, 4, 3>(a, s);
             case 8: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_ws_t<ET, 128, 224, 4, 2, 4, 3>(a, s);
             case 9: return launch_igemm_ws_t<ET, 64, 224, 2, 2, 4, 4>(a, s);
+            // 208 = 13 x 16 pixels: M = 2^10 * 49 k gives 484 (layer3, 2 cout tiles) or 244 (layer4, 4 cout tiles) tiles of 13 blocks
+            // where 224-wide tiles give 448 / 224 of 14: the same number of rounds on 256 CUs, 7 % less work per round
+            case 10: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_ws_t<ET, 128, 208, 4, 1, 4, 3>(a, s);
             default: return hipErrorInvalidValue;
         }
     }
