@@ -29,13 +29,12 @@ PyTorch is used for device memory, the stream, the dropout masks' random bits an
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, List, Optional, Tuple
 
 import torch
 
 from . import _lib
-from .model import _AR_BLOCKS, _GN_EPS, _GROUPS, _REG_HIDDEN, _REG_ITERS, PHDFor3DJoints, _round_up, expected_keys
+from .model import _GN_EPS, _GROUPS, _REG_HIDDEN, _REG_ITERS, PHDFor3DJoints, _round_up
 
 DROPOUT_P = 0.5        # ResidualBlock(dropout=0.5), JointRegressor(dropout=0.5): src/model.py:39,87
 
