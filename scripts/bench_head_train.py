@@ -1,6 +1,8 @@
 """Lifting-head phase-1 training step on one MI355X at train.py's configuration (PHD(1024, 17, 2), batch 32 x 40 frames, fp16,
 AdamW + GradScaler): steps/s, clips/s and the GEMM TFLOP/s of the step; eval forward beside it.  BASELINE configs[3], single GPU.
     python scripts/bench_head_train.py [--batch 32] [--steps 50]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/bench_head_train.py     # data parallel:
+        one process per GPU, every rank its own batch (weak scaling), ONE RCCL all-reduce of the flat fp32 gradient buffer per step
 """
 import argparse
 import json
@@ -24,9 +26,15 @@ def main():
     a = ap.parse_args()
     from implementation_phd_lab_vision_amd import train
     from implementation_phd_lab_vision_amd.model import expected_keys
-    dev = "cuda:0"
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
     d, nb = 1024, 2
-    g = torch.Generator().manual_seed(0)
+    g = torch.Generator().manual_seed(0)                  # the same initial weights on every rank
     sd = {k: torch.randn(*s, generator=g) * (0.02 if len(s) > 1 else 0.05) for k, s in expected_keys(d, 17, nb).items()}
     for k in sd:
         if ".gn" in k and k.endswith("weight"):
@@ -36,19 +44,29 @@ def main():
     m.load_state_dict(sd); m.to(dev).train()
     m.enable_graphs(not a.no_graph)
     optim, scaler = train.AdamW(m, lr=1e-4), train.GradScaler(init_scale=1024.0)
+    g = torch.Generator().manual_seed(100 + rank)         # every rank its own batch
     feats = torch.randn(a.batch, a.seq_len, 2048, generator=g).abs().to(dev)
     gt = (torch.randn(a.batch, a.seq_len, 17, 3, generator=g) * 0.5).to(dev)
     rows = a.batch * a.seq_len
     fwd = 2 * rows * (2048 * d + nb * 2 * 3 * d * d + 3 * ((d + 51) * 1024 + 1024 * 1024 + 1024 * 51))
     bwd = 2 * fwd - 2 * rows * 2048 * d          # dX and dW for every product except input_proj's dX
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
     for _ in range(a.warmup):
         m.train_step(feats, gt, optim, scaler)
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss, mpjpe, skipped = m.train_step(feats, gt, optim, scaler)
-    torch.cuda.synchronize()
+    fence()
     dt = (time.perf_counter() - t0) / a.steps
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
     m.eval()
     for _ in range(a.warmup):
         m(feats, predict_future=False)
@@ -58,10 +76,15 @@ def main():
         m(feats, predict_future=False)
     torch.cuda.synchronize()
     de = (time.perf_counter() - t0) / a.steps
-    print(json.dumps({"workload": f"PHD(1024,17,2) phase-1 train step, batch {a.batch} x {a.seq_len}, {a.precision}, AdamW + GradScaler, dropout on",
-                      "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt, "clips_per_s": a.batch / dt, "gemm_tflops": (fwd + bwd) / dt / 1e12,
+    if rank == 0:
+      print(json.dumps({"workload": f"PHD(1024,17,2) phase-1 train step, batch {a.batch} x {a.seq_len} per GPU, {a.precision}, AdamW + GradScaler, dropout on"
+                                    + (f", data parallel over {world} ranks (one all-reduce of {m.flat_grad.numel() * 4 / 1e6:.1f} MB per step)" if world > 1 else ""),
+                      "n_gpus": world, "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt, "clips_per_s": world * a.batch / dt, "gemm_tflops": world * (fwd + bwd) / dt / 1e12,
                       "gemm_flop_per_step": fwd + bwd, "last_loss": loss, "eval_forward_ms": de * 1e3,
                       "eval_forward_clips_per_s": a.batch / de, "trainable_params": int(m.flat_master.numel()), "hip_graph": not a.no_graph}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
