@@ -42,6 +42,8 @@ struct ConvLayer {
     float wscale = 1.0f;
     float* bias_scaled = nullptr;
     std::vector<float> bias_host;
+    std::vector<float> w_host;   // fp8 mode, conv3 / downsample of a stage's first block: folded fp32 weights (OIHW), requantised
+                                 // with a common accumulator scale once the activation scales are known
 };
 
 }  // namespace
@@ -59,6 +61,7 @@ struct r50_handle {
     int fused_stem = 1;                 // bf16 mode: conv1+bn1+relu+maxpool in one kernel
     int fuse_stem_c1 = 1;               // strip stem kernel also computes layer1.0.conv1
     std::vector<float> fp8_scales;      // R50_PREC_FP8: activation scales, execution order (r50_set_fp8_scales)
+    float cat_acc_scale[4] = {0.f, 0.f, 0.f, 0.f};   // fp8 two-source conv of layer2.0 / 3.0 / 4.0: real value of one accumulator unit
     int fuse_ds_cat = 1;                // layer2.0 / 3.0 / 4.0: conv3 and the downsample conv as one GEMM over K = [t2 | x at stride 2]
     __bf16* cat_w[4] = {nullptr, nullptr, nullptr, nullptr};      // per stage: (cout, cmid + cin) = [W3 | Wd], device
     float* cat_bias[4] = {nullptr, nullptr, nullptr, nullptr};    // b3 + bd (fp32)
@@ -197,6 +200,12 @@ float pack_ohwi_fp8(const float* wf, int cout, int cin, int ks, std::vector<uint
             for (int t = 0; t < ks * ks; ++t)
                 o[((size_t)oc * ks * ks + t) * cin + c] = f32_to_e4m3(wf[((size_t)oc * cin + c) * ks * ks + t] / scale);
     return scale;
+}
+
+inline float absmax_of(const std::vector<float>& v) {
+    float a = 0.f;
+    for (float x : v) a = std::fmax(a, std::fabs(x));
+    return a;
 }
 
 void pack_ohwi_bf16(const float* wf, int cout, int cin, int ks, std::vector<uint16_t>& out) {
@@ -844,14 +853,31 @@ int run_fp8_part(r50_handle* h, __bf16* const* buf, int cur, int n, float* out, 
             if ((rc = run_conv_fp8(h, c2, buf[fr[0]], n, h1, w1, nullptr, buf[fr[1]], 1, s_t1, 1.f, s_t2, s, &h2, &w2))) return rc;
             const void* idn = buf[cur];
             float s_idn = s_in;
+            const bool cat_ds = (b == 0) && h->fuse_ds_cat && h->cat_w[si] && h->cat_acc_scale[si] > 0.f;
             if (b == 0) {
-                const float s_ds = sc[k++];
-                int hd, wd;
-                if ((rc = run_conv_fp8(h, h->convs[li + 3], buf[cur], n, hh, ww, nullptr, buf[fr[2]], 0, s_in, 1.f, s_ds, s, &hd, &wd))) return rc;
-                idn = buf[fr[2]]; s_idn = s_ds;
+                const float s_ds = sc[k++];        // unused by the two-source form: the downsample tensor is never formed
+                if (!cat_ds) {
+                    int hd, wd;
+                    if ((rc = run_conv_fp8(h, h->convs[li + 3], buf[cur], n, hh, ww, nullptr, buf[fr[2]], 0, s_in, 1.f, s_ds, s, &hd, &wd))) return rc;
+                    idn = buf[fr[2]]; s_idn = s_ds;
+                }
             }
             const float s_out = sc[k++];
-            if ((rc = run_conv_fp8(h, c3, buf[fr[1]], n, h2, w2, idn, buf[fr[3]], 1, s_t2, s_idn, s_out, s, &h3, &w3))) return rc;
+            if (cat_ds) {
+                const ConvLayer& cd = h->convs[li + 3];
+                ConvArgs a;
+                rc = fill_conv_args_cat(a, buf[fr[1]], n, h2, w2, c3.cin / 2, buf[cur], hh, ww, cd.cin / 2, cd.stride, h->cat_w[si], h->cat_bias[si],
+                                        buf[fr[3]], c3.cout, 1);
+                if (rc) return fail(h, rc, "fp8 two-source conv args invalid for " + c3.conv_key);
+                a.y_bytes = (unsigned)((long long)a.M * c3.cout);
+                a.et = 2; a.oscale = h->cat_acc_scale[si] / s_out; a.rscale = 0.f;
+                const double flops = 2.0 * a.M * (double)a.Cout * (c3.cin + cd.cin);
+                prof_begin(h, s, r, PC_IGEMM, flops, (double)a.M * (c3.cin + cd.cin + a.Cout) + (double)a.Cout * (c3.cin + cd.cin), (int)(&c3 - &h->convs[0]));
+                hipError_t e = launch_igemm_fp8(a, 0, s);
+                prof_end(h, s, r);
+                if (e != hipSuccess) return fail(h, R50_ERR_HIP, "fp8 two-source igemm launch (" + c3.conv_key + "): " + hipGetErrorString(e));
+                h3 = h2; w3 = w2;
+            } else if ((rc = run_conv_fp8(h, c3, buf[fr[1]], n, h2, w2, idn, buf[fr[3]], 1, s_t2, s_idn, s_out, s, &h3, &w3))) return rc;
             cur = fr[3]; hh = h3; ww = w3; s_in = s_out;
             li += (b == 0) ? 4 : 3;
         }
@@ -1231,7 +1257,11 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
             if (split) pack_ohwi_split(wf.data(), L.cout, L.cin, L.ks, pk);
             else if (h->precision == R50_PREC_BF16W2) pack_ohwi_w2(wf.data(), L.cout, L.cin, L.ks, pk);
             else if (h->precision == R50_PREC_FP16) pack_ohwi_f16(wf.data(), L.cout, L.cin, L.ks, pk);
-            else if (h->precision == R50_PREC_FP8 && i >= kFp8FirstConv) L.wscale = pack_ohwi_fp8(wf.data(), L.cout, L.cin, L.ks, pk);
+            else if (h->precision == R50_PREC_FP8 && i >= kFp8FirstConv) {
+                L.wscale = pack_ohwi_fp8(wf.data(), L.cout, L.cin, L.ks, pk);
+                if (L.ks == 1 && (L.conv_key.find(".0.conv3") != std::string::npos || L.conv_key.find(".downsample.0") != std::string::npos))
+                    L.w_host = wf;
+            }
             else pack_ohwi_bf16(wf.data(), L.cout, L.cin, L.ks, pk);
             if (!L.w) HIP_TRY(h, hipMalloc((void**)&L.w, pk.size() * 2));
             HIP_TRY(h, hipMemcpy(L.w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
@@ -1293,7 +1323,32 @@ int r50_set_fp8_scales(r50_handle* h, const float* scales, int n) {
             if ((rc = set_bias(h->convs[li], s_in))) return rc;
             if ((rc = set_bias(h->convs[li + 1], s_t1))) return rc;
             if ((rc = set_bias(h->convs[li + 2], s_t2))) return rc;
-            if (b == 0) { ++k; if ((rc = set_bias(h->convs[li + 3], s_in))) return rc; }
+            if (b == 0) {
+                ++k;
+                if ((rc = set_bias(h->convs[li + 3], s_in))) return rc;
+                // conv3 + downsample as ONE fp8 accumulation over [t2 | x at the block's stride]: both products must land in the same
+                // accumulator unit, s = s_t2 * s_w3' = s_x * s_wd'.  s = the larger of the two natural units, so neither weight matrix
+                // clips; the other one is requantised a little coarser than its absmax would allow.
+                ConvLayer &c3 = h->convs[li + 2], &cd = h->convs[li + 3];
+                if (!c3.w_host.empty() && !cd.w_host.empty()) {
+                    const float a3 = absmax_of(c3.w_host), ad = absmax_of(cd.w_host);
+                    const float unit = std::fmax(s_t2 * (a3 > 0.f ? a3 / 448.0f : 1.0f), s_in * (ad > 0.f ? ad / 448.0f : 1.0f));
+                    const float sw3 = unit / s_t2, swd = unit / s_in;
+                    const int k1 = c3.cin, k2 = cd.cin, co = c3.cout;
+                    std::vector<uint8_t> cat((size_t)co * (k1 + k2));
+                    tmp.resize(co);
+                    for (int o = 0; o < co; ++o) {
+                        for (int c = 0; c < k1; ++c) cat[(size_t)o * (k1 + k2) + c] = f32_to_e4m3(c3.w_host[(size_t)o * k1 + c] / sw3);
+                        for (int c = 0; c < k2; ++c) cat[(size_t)o * (k1 + k2) + k1 + c] = f32_to_e4m3(cd.w_host[(size_t)o * k2 + c] / swd);
+                        tmp[o] = (c3.bias_host[o] + cd.bias_host[o]) / unit;
+                    }
+                    if (!h->cat_w[si]) HIP_TRY(h, hipMalloc((void**)&h->cat_w[si], cat.size()));
+                    if (!h->cat_bias[si]) HIP_TRY(h, hipMalloc((void**)&h->cat_bias[si], co * sizeof(float)));
+                    HIP_TRY(h, hipMemcpy(h->cat_w[si], cat.data(), cat.size(), hipMemcpyHostToDevice));
+                    HIP_TRY(h, hipMemcpy(h->cat_bias[si], tmp.data(), co * sizeof(float), hipMemcpyHostToDevice));
+                    h->cat_acc_scale[si] = unit;
+                }
+            }
             s_in = scales[k++];
             li += (b == 0) ? 4 : 3;
         }

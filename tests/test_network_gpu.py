@@ -386,6 +386,15 @@ def test_fp8_features_match_the_fp8_emulation(setup_fp8):
     # convs spread such flips; the device must stay as close to the emulation as the emulation's own error scale allows
     assert float(r_emu.max()) < 2.5e-2, r_emu
     assert float(r_ref.max()) < 1.5 * float(e_ref.max()) + 1e-2, (r_ref, e_ref)
+    # conv3 and the downsample conv as two launches (downsample tensor formed and rounded): its own emulation
+    bb.set_option("fuse_ds_cat", 0)
+    try:
+        f2 = bb(x.to("cuda:0")).flatten(1).cpu()
+    finally:
+        bb.set_option("fuse_ds_cat", 1)
+    emu2 = O.forward_fp8_emulated(sd, x, bb.fp8_scales, fused_ds=False)
+    assert float(O.per_row_rel_l2(f2, emu2).max()) < 2.5e-2
+    assert not torch.equal(f2, f)
 
 
 def test_fp8_mode_is_batch_independent_and_needs_scales(setup_fp8):
