@@ -33,6 +33,7 @@ import torch  # noqa: E402
 BATCH = 256
 GFLOP_PER_FRAME = 8.174272512          # 2 x 4,087,136,256 MAC, 53 convs
 MFMA_BF16_PEAK_TFLOPS = 2500.0         # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_FP8_PEAK_TFLOPS = 5000.0          # dense fp8 on the scaled K = 128 MFMA, same guide (--precision fp8 prices its igemm class against this)
 HBM_PEAK_GBPS = 8000.0                  # HBM3E, same guide
 HBM_PEAK_GBS = 8000.0
 
@@ -232,7 +233,8 @@ def main() -> None:
             except Exception:
                 traffic = None
         roofline = {"bound": "mfma", "kernel": "igemm_bf16_kernel + igemm_ws_kernel + conv3x3_c64_kernel (%d conv launches/step)" % round(ig["launches"] / max(1, args.steps)), "achieved": achieved,
-                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+                    "peak": (MFMA_FP8_PEAK_TFLOPS if args.precision == "fp8" else MFMA_BF16_PEAK_TFLOPS), "unit": "TFLOP/s",
+                    "frac": achieved / (MFMA_FP8_PEAK_TFLOPS if args.precision == "fp8" else MFMA_BF16_PEAK_TFLOPS),
                     "traffic": traffic,
                     "traffic_note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch, batch 256, from "
                                     "profiles/r01_pmc_hbm_traffic.json; algorithmic layer-wise bytes/launch = "
