@@ -189,6 +189,13 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned v) {   // max(x, 0) on 
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
 }
 
+// Cache-policy bits (aux) of the igemm epilogue's residual loads and output stores: 0 = default; 2 = nt.  A/B knobs (scripts/build_variant.sh).
+#ifndef R50_RES_AUX
+#define R50_RES_AUX 0
+#endif
+#ifndef R50_ST_AUX
+#define R50_ST_AUX 0
+#endif
 constexpr unsigned kOobOffset = 0x80000000u;
 
 template <int ET, int BC, int BP, int WC, int WP, int NSTAGE, bool SPLIT = false>
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
                 acc[2 * t][j] = b_lo;
                 acc[2 * t + 1][j] = b_hi;
                 if constexpr (PREFETCH_RES) if (has_res)     // row displacement in voffset: soffset is not part of the range check
-                    res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, 0);
+                    res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, R50_RES_AUX);
             }
         }
     };
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
                     if (has_res) {
                         u32x4 r;
                         if constexpr (PREFETCH_RES) r = res_reg[t][j];
-                        else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, 0, 0);
+                        else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, 0, R50_RES_AUX);
                         lo[0] += unpack_lo_e<ET>(r[0]); lo[1] += unpack_hi_e<ET>(r[0]);
                         lo[2] += unpack_lo_e<ET>(r[1]); lo[3] += unpack_hi_e<ET>(r[1]);
                         hi[0] += unpack_lo_e<ET>(r[2]); hi[1] += unpack_hi_e<ET>(r[2]);
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
 #pragma unroll
                         for (int e = 0; e < 4; ++e) out[e] = relu_bf16x2(out[e]);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, R50_ST_AUX);
                 } else {
                     // split mode: values travel as bf16 pairs (head, tail) with head + tail ~ fp32 (16 mantissa bits)
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -687,7 +694,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
                             const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_r, y_voff + j * y_rowstep + 32 * t, 0, 0);
                             res_reg[t][j] = (u32x4){r2[0], r2[1], 0u, 0u};
                         } else {
-                            res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, 0);
+                            res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, R50_RES_AUX);
                         }
                     }
                 }
@@ -761,7 +768,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
                     if (has_res) {
                         u32x4 r;
                         if constexpr (PREFETCH_RES) r = res_reg[t][j];
-                        else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, 0, 0);
+                        else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, 0, R50_RES_AUX);
                         lo[0] += unpack_lo_e<ET>(r[0]); lo[1] += unpack_hi_e<ET>(r[0]);
                         lo[2] += unpack_lo_e<ET>(r[1]); lo[3] += unpack_hi_e<ET>(r[1]);
                         hi[0] += unpack_lo_e<ET>(r[2]); hi[1] += unpack_hi_e<ET>(r[2]);
@@ -776,7 +783,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
 #if defined(R50_ABLATE_WS) && (R50_ABLATE_WS & 4)
                     if (out[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, 0);
 #else
-                    __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, R50_ST_AUX);
 #endif
                 }
             }
