@@ -27,21 +27,39 @@ class TensorDesc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("numel", C.c_int64)]
 
 
+def _source_digest() -> str:
+    """sha256 over everything the shared library is built from: csrc/*, include/r50.h and the compiler flags."""
+    import hashlib
+    hsh = hashlib.sha256()
+    files = sorted(p for p in CSRC.iterdir() if p.suffix in (".hip", ".h", ".hpp", ".cpp")) + [PKG_DIR.parent / "include" / "r50.h"]
+    for f in files:
+        hsh.update(f.name.encode() + b"\0")
+        hsh.update(f.read_bytes())
+    hsh.update(" ".join(HIPCC_FLAGS).encode())
+    return hsh.hexdigest()
+
+
 def build_library(force: bool = False, verbose: bool = False) -> Path:
-    """Compile csrc/r50_abi.hip for gfx950 into libr50hip.so (in-tree)."""
-    srcs = [CSRC / "r50_abi.hip", CSRC / "kernels.h", PKG_DIR.parent / "include" / "r50.h"]
+    """Compile csrc/r50_abi.hip for gfx950 into libr50hip.so (in-tree).  The library is reused only if the digest
+    stored beside it (libr50hip.so.sha256) equals the digest of the sources + flags it would be built from now:
+    a stale binary is rebuilt whatever its mtime says."""
     if "R50_LIB" in os.environ:
         return LIB_PATH
-    if LIB_PATH.exists() and not force:
-        if all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs if s.exists()):
-            return LIB_PATH
+    stamp = LIB_PATH.with_name(LIB_PATH.name + ".sha256")
+    digest = _source_digest()
+    if LIB_PATH.exists() and not force and stamp.exists() and stamp.read_text().strip() == digest:
+        return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(LIB_PATH), str(CSRC / "r50_abi.hip")]
+    tmp = LIB_PATH.with_name(LIB_PATH.name + f".tmp{os.getpid()}")
+    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(tmp), str(CSRC / "r50_abi.hip")]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        tmp.unlink(missing_ok=True)
         raise R50Error(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    os.replace(tmp, LIB_PATH)             # atomic: concurrent ranks never dlopen a half-written file
+    stamp.write_text(digest + "\n")
     return LIB_PATH
 
 

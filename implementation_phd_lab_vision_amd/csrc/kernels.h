@@ -1348,6 +1348,296 @@ __global__ __launch_bounds__(512) void bneck_tail2_kernel(const Tail2Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Bottleneck tail (layer3): conv3 1x1 (256 -> 1024) + bn3 + identity + ReLU and the NEXT block's conv1 1x1 (1024 -> 256) + bn1 + ReLU
+// CHAINED inside one launch (src/preprocess_resnet_features.py:296 -> torchvision Bottleneck.forward: `out = relu(bn3(conv3(out)) +
+// identity)` of block b, `relu(bn1(conv1(x)))` of block b+1).
+// Why: at 14x14 both convs are HBM-phase / MFMA-phase alternators (conv3: 59 us at 3.9 TB/s, conv1: 37 us at 3.4 TB/s, batch 256).
+// Chained, the 103 MB block output is written once and never read back by conv1, and one launch boundary disappears.
+// The weights (2 x 512 KB) do not fit LDS or registers, so -- unlike the layer1 / layer2 tails -- they STREAM through an LDS ring
+// filled by loader waves (the igemm_ws_kernel scheme), and the chain runs over 128-channel CHUNKS c of the block output:
+//     A(c):  accA[128 x P] = b3[c] + W3[c] . t2          4 K-steps of 64; the pixel tile's t2 rows stay RESIDENT in LDS for the tile
+//     I(c):  accA += res[c]                              the residual rows arrive by loader DMA like any operand (no vector-memory load
+//            in the consumer waves); each lane reads its 8 channels back from LDS and adds them with the very fp32 additions of the
+//            igemm epilogue (an MFMA against an identity operand would be cheaper, but its accumulate differs from fl(a + b) in ~1e-7
+//            of the elements)
+//     E(c):  relu, 16-bit, -> HBM (block output) and -> LDS as the B operand `out_c` (P rows x 256 B)
+//     B(c):  accB[256 x P] += W1[:, c] . out_c           2 K-slots x 2 cout halves; accB stays in registers across the 8 chunks
+// and, after chunk 7, y1n = relu(accB) (accB started at b1).  Summation orders are those of the igemm launches this replaces
+// (bias first, K ascending, residual last), so both outputs are bit-identical to them.
+// Geometry: P = 112 pixel rows in LDS (7 MFMA column blocks), of which the first `bp` are real (bp = 98 at batch 256: 512 tiles =
+// two full rounds of 256 CUs); 4 consumer waves (wave w: couts 32w.. of a 128-row W slice; all 112 pixels) + 4 loader waves.
+// A CU takes in at most ~40 B/clk from L2, so what is staged per MFMA cycle decides the speed: every ring stage is 16 KB = 4 LDS-DMA
+// instructions per loader wave against 28 MFMAs per consumer wave:
+//     T step (4 per tile): t2 rows, K-slot k -> the resident T2 region        A step: W3 slice [128 rows x 64 K]
+//     I step (2 per chunk): residual rows, slot s (waves 2s, 2s+1 consume)     B step: W1 slice [128 rows (half h) x 64 K (slot kb)]
+// (rows of 128 B, 16-B chunk c of row r at chunk c ^ (r & 7), as in the igemm kernels).  LDS: ring 4 x 16 KB (3 stages in flight) +
+// T2 4 x 14 KB + out_c 2 x 14 KB + b1, b3 = 156,672 B.  4 + 8 x 10 = 84 steps (barriers) per tile.
+// ------------------------------------------------------------------------------------------------
+struct Tail3Args {
+    const __bf16* y2;     // (M, 256)   conv2 output
+    const __bf16* w3;     // (1024, 256) folded conv3 weights, K contiguous
+    const float* b3;      // (1024)
+    const __bf16* res;    // (M, 1024)  identity
+    __bf16* out;          // (M, 1024)  block output
+    const __bf16* w1;     // (256, 1024) folded weights of the next block's conv1
+    const float* b1;      // (256)
+    __bf16* y1n;          // (M, 256)   next block's conv1 output
+    int M;
+    int bp;               // real pixels per tile (<= 112)
+    int n_tiles;          // ceil(M / bp)
+};
+
+template <int ET>
+__global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int CMID = 256, COUT = 1024, C1N = 256;
+    constexpr int NCH = COUT / 128;               // chunks of 128 block-output channels
+    constexpr int KA = CMID / 64;                 // K-slots of t2 = T steps per tile = A steps per chunk
+    constexpr int SPC = KA + 2 + 4;               // steps per chunk: A x4, I x2, B x4
+    constexpr int SPT = KA + NCH * SPC;           // steps per tile
+    constexpr int PR = 112, NR = 7;               // pixel rows held in LDS / MFMA column blocks
+    constexpr int STAGE = 16384, NSTAGE = 4, D = NSTAGE - 1, LPS = 4;    // LDS-DMA instructions per loader wave per stage
+    constexpr int T2 = NSTAGE * STAGE;            // resident t2 tile: 4 K-slots of 128 rows (112 + 16 pad rows the DMA zero-fills)
+    constexpr int T2_SLOT = PR * 128;             // 14 KB: the 4th DMA pass of loader waves 2, 3 (rows 112..127) is redirected, see below
+    constexpr int OUTC = T2 + KA * T2_SLOT, OUTC_SLOT = PR * 128;
+    constexpr int B1_OFF = OUTC + 2 * OUTC_SLOT, B3_OFF = B1_OFF + C1N * 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grid = gridDim.x;
+    const int first = blockIdx.x;
+    const int my_tiles = (a.n_tiles - first + grid - 1) / grid;
+    const int total = my_tiles * SPT;
+
+    if (tid < C1N) {                              // both bias vectors live in LDS: no bias registers, no vector-memory loads in the consumers
+        reinterpret_cast<float*>(smem + B1_OFF)[tid] = a.b1[tid];
+        reinterpret_cast<f32x4*>(smem + B3_OFF)[tid] = reinterpret_cast<const f32x4*>(a.b3)[tid];
+    }
+
+    if (wave >= 4) {
+        // =============================== loader waves ===============================================
+        const int lw = wave - 4;
+        const int lt = tid - 256;
+        const int srow = lt >> 3, slot = lt & 7;
+        const int lchunk = slot ^ (srow & 7);
+        const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w3), 0, COUT * CMID * 2u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w1), 0, C1N * COUT * 2u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.y2), 0, (unsigned)a.M * (CMID * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.M * (COUT * 2u), 0x00020000);
+        unsigned w3_voff[4], w1_voff[4], y2_voff[4], res_voff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {             // LDS row rho holds channel perm(rho) of its 32-row group (8 consecutive couts per lane)
+            const int rho = i * 32 + srow;
+            const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+            w1_voff[i] = (unsigned)(cl * COUT + lchunk * 8) * 2u;
+            w3_voff[i] = (unsigned)(cl * CMID + lchunk * 8) * 2u;
+        }
+        auto decode_tile = [&](int tile) {
+            const int p0 = tile * a.bp;
+            const int limit = (a.M - p0 < a.bp) ? a.M - p0 : a.bp;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int prow = i * 32 + srow;
+                const bool ok = prow < limit;          // rows past the tile's pixels (and the 16 pad rows) read as zeros
+                y2_voff[i] = ok ? (unsigned)((p0 + prow) * CMID + lchunk * 8) * 2u : kOobOffset;
+                res_voff[i] = ok ? (unsigned)((p0 + prow) * COUT + lchunk * 8) * 2u : kOobOffset;
+            }
+        };
+        int i_tile = first, i_c = -1, i_s = 0, i_buf = 0;      // i_c == -1: the tile's T steps
+        decode_tile(i_tile);
+        auto stage_issue = [&]() {
+            char* sbase = smem + i_buf * STAGE + lw * 1024;
+            if (i_c < 0) {                                                     // T: t2 rows, K-slot i_s -> resident region
+                // slots are 112 rows: the last pass of loader waves 2, 3 would write rows 112..127 = the next slot, so it goes (as a
+                // zero fill: those rows are always out of range) to this step's ring stage, which a T step does not use.  Every wave
+                // still issues LPS instructions per step: the counted vmcnt waits depend on it.
+                char* tb = smem + T2 + i_s * T2_SLOT + lw * 1024;
+                const int xofs = __builtin_amdgcn_readfirstlane(i_s * 128);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y2, (LDS_AS void*)((i == 3 && lw >= 2) ? sbase : tb + i * 4096), 16, y2_voff[i], xofs, 0, 0);
+            } else if (i_s < KA) {                                             // A: W3 rows of chunk i_c, K-slot i_s
+                const int wofs = __builtin_amdgcn_readfirstlane(i_c * (128 * CMID * 2) + i_s * 128);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (LDS_AS void*)(sbase + i * 4096), 16, w3_voff[i], wofs, 0, 0);
+            } else if (i_s < KA + 2) {                                         // I: residual rows, channels 128 i_c + 64 s ..
+                const int rofs = __builtin_amdgcn_readfirstlane(i_c * 256 + (i_s - KA) * 128);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(sbase + i * 4096), 16, res_voff[i], rofs, 0, 0);
+            } else {                                                           // B: W1 rows 128 h .., K = 128 i_c + 64 kb ..
+                const int bs = i_s - KA - 2, kb = bs >> 1, hh = bs & 1;
+                const int wofs = __builtin_amdgcn_readfirstlane(hh * (128 * COUT * 2) + i_c * 256 + kb * 128);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (LDS_AS void*)(sbase + i * 4096), 16, w1_voff[i], wofs, 0, 0);
+            }
+            i_buf = (i_buf + 1) & (NSTAGE - 1);
+            ++i_s;
+            if (i_c < 0) {
+                if (i_s == KA) { i_s = 0; i_c = 0; }
+            } else if (i_s == SPC) {
+                i_s = 0;
+                if (++i_c == NCH) {
+                    i_c = -1;
+                    i_tile += grid;
+                    if (i_tile < a.n_tiles) decode_tile(i_tile);
+                }
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < D; ++s) stage_issue();           // total is a multiple of 84 (>= D)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPS) : "memory");      // step 0 landed
+        __builtin_amdgcn_s_barrier();             // pairs with the consumers' first barrier
+        for (int g = 0; g < total; ++g) {
+            if (g + D < total) stage_issue();
+            // steps issued so far: 0 .. min(g+D, total-1); step g+1 must be complete before the barrier ending step g
+            if (g + D < total) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPS) : "memory");
+            } else if (g + D - 1 < total) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * LPS) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        // =============================== consumer waves =============================================
+        const int w = wave;
+        const int fr = lane & 15, fq = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.M * (COUT * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.M * (C1N * 2u), 0x00020000);
+        const int fphys0 = (fq ^ (fr & 7)) << 4;                       // kk = 0; kk = 1 is ^ 64
+        const int w_frag = (32 * w + fr) * 128;                         // + m*2048: this wave's 32 rows of a 128-row W slice
+        const int x_frag = fr * 128;                                    // + j*2048
+        // the wave's channels 32w .. 32w+31 of a chunk: slot w>>1, 16-B chunks 4(w&1) + fq of a pixel row (residual in, out_c out)
+        const int c_frag = x_frag + (((4 * (w & 1) + fq) ^ (fr & 7)) << 4);
+        f32x4 accA[2][NR], accB[4][NR];
+        // one W-slice step: acc[m][j] += W[32w + 16m ..][64 K] . X[64 K][16 j ..]; a single set of pixel fragments (the kernel sits at the
+        // 256-register limit): the K = 32..63 fragment of pixel block j replaces the K = 0..31 one as soon as that block's MFMAs are
+        // issued and is consumed 14 MFMAs later (order pinned with sched_group_barrier)
+        auto w_step = [&](const char* wb, const char* xb, f32x4 (&acc0)[NR], f32x4 (&acc1)[NR]) {
+            bf16x8 x[NR], w0[2], w1[2];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) x[j] = *reinterpret_cast<const bf16x8*>(xb + x_frag + j * 2048 + fphys0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) w0[m] = *reinterpret_cast<const bf16x8*>(wb + w_frag + m * 2048 + fphys0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) w1[m] = *reinterpret_cast<const bf16x8*>(wb + w_frag + m * 2048 + (fphys0 ^ 64));
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                acc0[j] = mfma_e<ET>(w0[0], x[j], acc0[j]);
+                acc1[j] = mfma_e<ET>(w0[1], x[j], acc1[j]);
+                x[j] = *reinterpret_cast<const bf16x8*>(xb + x_frag + j * 2048 + (fphys0 ^ 64));
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                acc0[j] = mfma_e<ET>(w1[0], x[j], acc0[j]);
+                acc1[j] = mfma_e<ET>(w1[1], x[j], acc1[j]);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, NR + 4, 0);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NR, 0);
+            // the barrier stays BEHIND the step's last MFMA, i.e. behind the lgkmcnt(0) that MFMA needs: every fragment read of this
+            // stage has returned before the loaders may refill it (hoisted above the MFMAs, reads could still be in flight)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        int c_buf = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's part of the biases is in LDS ...
+        __builtin_amdgcn_s_barrier();             // ... and after the barrier everybody's; step 0 landed
+        for (int tile = first; tile < a.n_tiles; tile += grid) {
+            const int p0 = tile * a.bp;
+            const int limit = (a.M - p0 < a.bp) ? a.M - p0 : a.bp;
+#pragma unroll
+            for (int k = 0; k < KA; ++k) {        // T steps: the loaders bring the tile's t2 rows in; nothing to compute
+                c_buf = (c_buf + 1) & (NSTAGE - 1);
+                __builtin_amdgcn_s_barrier();
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {         // accB[2t + e]: channels 128t + 32w + 8fq + 4e ..
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + B1_OFF + (128 * t + 32 * w + 8 * fq) * 4);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + B1_OFF + (128 * t + 32 * w + 8 * fq + 4) * 4);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) { accB[2 * t][j] = lo; accB[2 * t + 1][j] = hi; }
+            }
+            for (int c = 0; c < NCH; ++c) {
+                {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + B3_OFF + (c * 128 + 32 * w + 8 * fq) * 4);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + B3_OFF + (c * 128 + 32 * w + 8 * fq + 4) * 4);
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) { accA[0][j] = lo; accA[1][j] = hi; }
+                }
+                // ---- A: 4 K-slots of W3[c] . t2
+                for (int k = 0; k < KA; ++k) {
+                    w_step(smem + c_buf * STAGE, smem + T2 + k * T2_SLOT, accA[0], accA[1]);
+                    c_buf = (c_buf + 1) & (NSTAGE - 1);
+                }
+                // ---- I: + identity (waves 2s, 2s+1 in step s), then E: ReLU, 16-bit, to HBM and to LDS (B operand of the second GEMM)
+#pragma unroll
+                for (int sI = 0; sI < 2; ++sI) {
+                    if (sI == (w >> 1)) {
+                        const char* sb = smem + c_buf * STAGE;
+                        u32x4 r[NR];
+#pragma unroll
+                        for (int j = 0; j < NR; ++j) r[j] = *reinterpret_cast<const u32x4*>(sb + c_frag + j * 2048);
+                        const int cofs = __builtin_amdgcn_readfirstlane(c * 256);
+                        // store offsets are recomputed per chunk from an opaque copy of the lane's pixel: hoisted out of the chunk loop they
+                        // would pin 7 more registers for the whole tile
+                        int pix = fr;
+                        asm volatile("" : "+v"(pix));
+#pragma unroll
+                        for (int j = 0; j < NR; ++j) {
+                            f32x4 lo = accA[0][j], hi = accA[1][j];
+                            lo[0] += unpack_lo_e<ET>(r[j][0]); lo[1] += unpack_hi_e<ET>(r[j][0]);
+                            lo[2] += unpack_lo_e<ET>(r[j][1]); lo[3] += unpack_hi_e<ET>(r[j][1]);
+                            hi[0] += unpack_lo_e<ET>(r[j][2]); hi[1] += unpack_hi_e<ET>(r[j][2]);
+                            hi[2] += unpack_lo_e<ET>(r[j][3]); hi[3] += unpack_hi_e<ET>(r[j][3]);
+                            u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                            *reinterpret_cast<u32x4*>(smem + OUTC + (w >> 1) * OUTC_SLOT + c_frag + j * 2048) = o;
+                            const unsigned voff = (16 * j + pix < limit) ? (unsigned)((p0 + 16 * j + pix) * COUT + 32 * w + 8 * fq) * 2u : kOobOffset;
+                            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, voff, cofs, 0);
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // out_c written before anybody reads it
+                    }
+                    c_buf = (c_buf + 1) & (NSTAGE - 1);
+                    __builtin_amdgcn_s_barrier();
+                }
+                // ---- B: W1[:, c] . out_c, K-slot kb x cout half h
+#pragma unroll
+                for (int bs = 0; bs < 4; ++bs) {
+                    w_step(smem + c_buf * STAGE, smem + OUTC + (bs >> 1) * OUTC_SLOT, accB[2 * (bs & 1)], accB[2 * (bs & 1) + 1]);
+                    c_buf = (c_buf + 1) & (NSTAGE - 1);
+                }
+            }
+            // ---- next conv1's output: ReLU, 16-bit, 16-B stores
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const f32x4 lo = accB[2 * t][j], hi = accB[2 * t + 1][j];
+                    u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                    const unsigned voff = (16 * j + fr < limit) ? (unsigned)((p0 + 16 * j + fr) * C1N + 128 * t + 32 * w + 8 * fq) * 2u : kOobOffset;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, voff, 0, 0);
+                }
+        }
+    }
+#else
+    (void)a;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Frame producer: crop box + bilinear resize of decoded uint8 frames, on the device.
 // Reference: _crop_and_resize_video_uint8 (src/dataset.py:141-149) = slice [top:top+hh, left:left+ww] of the
 // (T,H,W,3) clip, then torchvision resize(..., [224,224], antialias=False) on uint8, which on an AVX2 CPU is ATen's

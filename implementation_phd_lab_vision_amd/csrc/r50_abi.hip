@@ -22,8 +22,8 @@ struct Prof {
     int64_t launches = 0;
     double ms = 0, flops = 0, bytes = 0;
 };
-enum ProfClass { PC_IGEMM = 0, PC_STEM_CONV, PC_MAXPOOL, PC_AVGPOOL, PC_STEM_PACK, PC_TAIL, PC_COUNT };
-const char* kProfNames[PC_COUNT] = {"igemm", "conv1", "maxpool", "avgpool", "stem_pack", "bneck_tail"};
+enum ProfClass { PC_IGEMM = 0, PC_STEM_CONV, PC_MAXPOOL, PC_AVGPOOL, PC_STEM_PACK, PC_TAIL, PC_TAIL3, PC_COUNT };
+const char* kProfNames[PC_COUNT] = {"igemm", "conv1", "maxpool", "avgpool", "stem_pack", "bneck_tail", "bneck_tail3"};
 
 struct EvRec {
     hipEvent_t a, b;
@@ -66,6 +66,7 @@ struct r50_handle {
     __bf16* cat_w[4] = {nullptr, nullptr, nullptr, nullptr};      // per stage: (cout, cmid + cin) = [W3 | Wd], device
     float* cat_bias[4] = {nullptr, nullptr, nullptr, nullptr};    // b3 + bd (fp32)
     int fuse_tail = 1;                  // bf16 mode, layer1: conv3 + identity + ReLU + the next block's conv1 in one kernel
+    int fuse_tail3 = 1;                 // layer3.1-.4: conv3 + identity + ReLU chained with the next block's conv1 through LDS (bneck_tail3_kernel)
     int n_streams = 1;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -629,6 +630,36 @@ hipError_t launch_bneck_tail2(const void* y2, long long m, const void* w3, const
     return hipGetLastError();
 }
 
+// layer3 shapes: conv3 (256 -> 1024) + identity + ReLU chained with the next conv1 (1024 -> 256) (kernels.h: bneck_tail3_kernel)
+// Pixel tile: at most 112 rows; chosen so the tiles fill whole rounds of the chip (batch 256: M = 50,176 -> 98 pixels, 512 tiles).
+hipError_t launch_bneck_tail3(const void* y2, long long m, const void* w3, const float* b3, const void* res, void* out,
+                              const void* w1, const float* b1, void* y1n, hipStream_t s, int et = 0, int bp_override = 0) {
+    if (!y2 || !w3 || !b3 || !res || !out || !w1 || !b1 || !y1n || m <= 0 || m * 2048 >= (1ll << 31)) return hipErrorInvalidValue;
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        g_num_cus = prop.multiProcessorCount;
+    }
+    Tail3Args a;
+    a.y2 = (const __bf16*)y2; a.w3 = (const __bf16*)w3; a.b3 = b3; a.res = (const __bf16*)res; a.out = (__bf16*)out;
+    a.w1 = (const __bf16*)w1; a.b1 = b1; a.y1n = (__bf16*)y1n; a.M = (int)m;
+    const long long rounds = ((m + 111) / 112 + g_num_cus - 1) / g_num_cus;
+    long long bp = (m + rounds * g_num_cus - 1) / (rounds * g_num_cus);
+    if (bp < 49) bp = 49;
+    if (bp > 112) bp = 112;
+    if (bp_override >= 1 && bp_override <= 112) bp = bp_override;
+    a.bp = (int)bp;
+    a.n_tiles = (int)((m + bp - 1) / bp);
+    const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
+    const size_t lds = 4 * 16384 + 4 * 112 * 128 + 2 * 112 * 128 + 256 * 4 + 1024 * 4;      // ring + resident t2 + out_c + b1 + b3
+    auto kern = et == 1 ? bneck_tail3_kernel<1> : bneck_tail3_kernel<0>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, int ww, const __bf16* res,
              __bf16* y, int relu, hipStream_t s, int* ho, int* wo) {
     ConvArgs a;
@@ -985,6 +1016,7 @@ after_pool:
             const bool fuse_ok = !split && !nx_is_fp8 && (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16 || h->precision == R50_PREC_FP8) && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
                                  nx->ks == 1 && nx->stride == 1;
             const bool fuse2 = fuse_ok && c3.cin == 128 && c3.cout == 512 && nx->cin == 512 && nx->cout == 128;   // layer2 shapes
+            const bool fuse3 = fuse_ok && h->fuse_tail3 && b > 0 && c3.cin == 256 && c3.cout == 1024 && nx->cin == 1024 && nx->cout == 256;   // layer3 shapes (plain identity)
             const ConvLayer* cdp = (b == 0) ? &h->convs[li + 3] : nullptr;
             // layer2.0 / 3.0 / 4.0: conv3 + downsample + add + ReLU as ONE 1x1 conv over K = [t2 | block input at the block's stride]
             // against [W3 | Wd]: the downsample tensor is never written or read back, and there is one launch instead of two.
@@ -992,7 +1024,7 @@ after_pool:
             const bool cat_ds = (b == 0) && si >= 1 && !split && h->fuse_ds_cat && h->cat_w[si] && h->tile_override == 0 &&
                                 cdp && cdp->ks == 1 && c3.ks == 1 && !(tap && p + ".ds" == tap);
             const bool fuse = !cat_ds && ((fuse_ok && c3.cin == 64 && c3.cout == 256 && nx->cin == 256 && (nx->cout == 64 || nx->cout == 128)) ||
-                                          fuse2);
+                                          fuse2 || fuse3);
             const bool fuse_ds = fuse && cdp && cdp->ks == 1 && cdp->stride == 1 && cdp->cin == 64 && cdp->cout == 256 &&
                                  !(tap && p + ".ds" == tap);
             const bool ds_side = (b == 0) && h->overlap_ds && !h->profile && !tap && !fuse_ds && !cat_ds;
@@ -1035,11 +1067,13 @@ after_pool:
             if (fuse) {
                 const long long m = (long long)n * h2 * w2;
                 EvRec rt{};
-                prof_begin(h, s, rt, PC_TAIL, 2.0 * m * ((double)c3.cout * c3.cin * (fuse_ds ? 2 : 1) + (double)nx->cout * nx->cin),
+                prof_begin(h, s, rt, fuse3 ? PC_TAIL3 : PC_TAIL, 2.0 * m * ((double)c3.cout * c3.cin * (fuse_ds ? 2 : 1) + (double)nx->cout * nx->cin),
                            2.0 * (m * ((double)c3.cin + (fuse_ds ? c3.cin : c3.cout) + c3.cout + nx->cout) +
                                   (double)c3.cout * c3.cin * (fuse_ds ? 2 : 1) + (double)nx->cin * nx->cout),
                            (int)(&c3 - &h->convs[0]));
-                if (fuse2)
+                if (fuse3)
+                    e = launch_bneck_tail3(buf[fr[1]], m, c3.w, c3.bias, idn, buf[fr[3]], nx->w, nx->bias, buf[fr[0]], s, et);
+                else if (fuse2)
                     e = launch_bneck_tail2(buf[fr[1]], m, c3.w, c3.bias, idn, buf[fr[3]], nx->w, nx->bias, buf[fr[0]], s, et);
                 else
                     e = launch_bneck_tail(buf[fr[1]], m, c3.w, c3.bias, fuse_ds ? buf[cur] : idn, fuse_ds ? cdp->w : nullptr,
@@ -1388,6 +1422,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "tile") h->tile_override = (int)value;
     else if (k == "fused_stem") h->fused_stem = value ? 1 : 0;
     else if (k == "fuse_tail") h->fuse_tail = value ? 1 : 0;
+    else if (k == "fuse_tail3") h->fuse_tail3 = value ? 1 : 0;
     else if (k == "fuse_stem_c1") h->fuse_stem_c1 = value ? 1 : 0;
     else if (k == "fuse_ds_cat") h->fuse_ds_cat = value ? 1 : 0;
     else if (k == "stem_strip") {          // process-wide (the launcher is shared by the handle and the r50_op_* hooks)
@@ -1409,6 +1444,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "streams") *value = h->n_streams;
     else if (k == "fused_stem") *value = h->fused_stem;
     else if (k == "fuse_tail") *value = h->fuse_tail;
+    else if (k == "fuse_tail3") *value = h->fuse_tail3;
     else if (k == "fuse_stem_c1") *value = h->fuse_stem_c1;
     else if (k == "fuse_ds_cat") *value = h->fuse_ds_cat;
     else if (k == "stem_strip") *value = g_stem_strip;
@@ -1547,6 +1583,10 @@ int r50_op_bneck_tail(const void* y2, int64_t m, int cmid, const void* w3, const
     hipError_t e;
     if (cmid == 64) e = launch_bneck_tail(y2, m, w3, b3, res, wd, bd, out, w1, c1, b1, y1n, (hipStream_t)stream);
     else if (cmid == 128 && c1 == 128 && !wd && !bd) e = launch_bneck_tail2(y2, m, w3, b3, res, out, w1, b1, y1n, (hipStream_t)stream);
+    else if (cmid == 256 && c1 == 256 && !wd && !bd) {
+        const char* v = std::getenv("R50_TAIL3_BP");          // test / A-B knob of this debug hook: real pixels per tile (1..112); unset = automatic
+        e = launch_bneck_tail3(y2, m, w3, b3, res, out, w1, b1, y1n, (hipStream_t)stream, 0, v ? std::atoi(v) : 0);
+    }
     else e = hipErrorInvalidValue;
     if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
                                      std::string("r50_op_bneck_tail: ") + hipGetErrorString(e));

@@ -132,10 +132,12 @@ def conv1x1_cat(x1: torch.Tensor, x2: torch.Tensor, stride2: int, wcat: torch.Te
 
 
 def bneck_tail_bf16(y2: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, identity: torch.Tensor, w1: torch.Tensor,
-                    b1: torch.Tensor, wd: Optional[torch.Tensor] = None, bd: Optional[torch.Tensor] = None):
+                    b1: torch.Tensor, wd: Optional[torch.Tensor] = None, bd: Optional[torch.Tensor] = None,
+                    out: Optional[torch.Tensor] = None, y1n: Optional[torch.Tensor] = None):
     """Fused tail of a bottleneck: ``out = relu(conv3(y2) + b3 + identity)`` and the next block's
     ``y1n = relu(conv1(out) + b1)``.  y2 (...,cmid), w3 (4*cmid,cmid) / w1 (c1,4*cmid) folded bf16, biases fp32 ->
-    (out (...,4*cmid), y1n (...,c1)) bf16; cmid = 64 (layer1) or 128 (layer2, c1 = 128).  ``identity`` is the
+    (out (...,4*cmid), y1n (...,c1)) bf16; cmid = 64 (layer1), 128 (layer2, c1 = 128) or 256 (layer3, c1 = 256: the chained
+    kernel, weights streamed through LDS).  ``out`` / ``y1n``: optional preallocated outputs.  ``identity`` is the
     (...,4*cmid) identity tensor, or -- cmid = 64 with the folded downsample weights ``wd`` (256,64) / ``bd`` --
     the (...,64) block input."""
     for t, n in ((y2, "y2"), (w3, "w3"), (identity, "identity"), (w1, "w1")):
@@ -155,8 +157,13 @@ def bneck_tail_bf16(y2: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, identi
     if identity.shape[-1] != cid or identity.numel() != m * cid or tuple(w3.shape) != (cout, cmid) \
             or tuple(w1.shape) != (c1, cout) or b3.numel() != cout or b1.numel() != c1:
         raise ValueError("bneck_tail_bf16: inconsistent shapes")
-    out = torch.empty(tuple(y2.shape[:-1]) + (cout,), dtype=torch.bfloat16, device=y2.device)
-    y1n = torch.empty(tuple(y2.shape[:-1]) + (c1,), dtype=torch.bfloat16, device=y2.device)
+    if out is None:
+        out = torch.empty(tuple(y2.shape[:-1]) + (cout,), dtype=torch.bfloat16, device=y2.device)
+    if y1n is None:
+        y1n = torch.empty(tuple(y2.shape[:-1]) + (c1,), dtype=torch.bfloat16, device=y2.device)
+    _need(out, torch.bfloat16, "out"); _need(y1n, torch.bfloat16, "y1n")
+    if out.numel() != m * cout or y1n.numel() != m * c1:
+        raise ValueError("bneck_tail_bf16: output tensors have the wrong size")
     with torch.cuda.device(y2.device):
         rc = _lib.load_library().r50_op_bneck_tail(y2.data_ptr(), m, cmid, w3.data_ptr(), b3.data_ptr(), identity.data_ptr(),
                                                    wd.data_ptr() if wd is not None else None,

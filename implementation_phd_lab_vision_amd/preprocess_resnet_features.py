@@ -13,9 +13,9 @@ RCCL gather of the feature blocks instead of ``nn.DataParallel`` (distributed.py
 
 The clip dataset is the reference's own ``Human36MPreprocessedClips`` (src/dataset.py), imported from
 ``$H36M_REFERENCE_SRC`` or ``sys.path`` — the frame producer is upstream of this path.  Extra,
-optional flags (defaults keep the reference behaviour): ``--weights`` (local torchvision checkpoint;
-otherwise seeded synthetic weights — nothing is downloaded), ``--synthetic-clips N`` (run without
-H36M data), ``--precision {bf16,fp16,bf16w2,fp32x,fp8}``, ``--micro-batch``, ``--max-batch``.
+flags: ``--weights PATH`` (local torchvision checkpoint; nothing is downloaded) — REQUIRED unless
+``--synthetic-weights`` (seeded random weights, benchmarks / tests only) is given; ``--synthetic-clips N``
+(run without H36M data), ``--precision {bf16,fp16,bf16w2,fp32x,fp8}``, ``--micro-batch``, ``--max-batch``.
 """
 from __future__ import annotations
 
@@ -52,7 +52,12 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--shuffle-pool", type=int, default=8192, help="Clips accumulated before a shuffle + flush")
     p.add_argument("--shuffle-seed", type=int, default=123, help="Seed for clip-level shuffling")
     # ---- additions (optional) ----
-    p.add_argument("--weights", type=str, default=None, help="Local torchvision resnet50-*.pth (default: seeded synthetic)")
+    p.add_argument("--weights", type=str, default=None,
+                   help="Local torchvision-layout ResNet-50 checkpoint (e.g. resnet50-11ad3fa6.pth = IMAGENET1K_V2, what the reference "
+                        "downloads at :207).  Required unless --synthetic-weights is given: nothing is downloaded here")
+    p.add_argument("--synthetic-weights", action="store_true",
+                   help="Run with seeded RANDOM backbone weights (--weights-seed): for benchmarks / tests only -- the shards then hold "
+                        "features of an untrained network")
     p.add_argument("--weights-seed", type=int, default=0)
     p.add_argument("--synthetic-clips", type=int, default=0, help="Use N synthetic clips instead of reading --root")
     p.add_argument("--precision", choices=["bf16", "fp16", "bf16w2", "fp32x", "fp8"], default="bf16",
@@ -95,6 +100,33 @@ def _open_dataset(args):
     return Human36MPreprocessedClips(root=args.root, subjects=args.subjects, seq_len=args.seq_len,
                                      frame_skip=args.frame_skip, stride=args.stride, augment=args.augment,
                                      max_clips=None)
+
+
+def _resolve_weights(args):
+    """The reference's ``models.resnet50(weights=IMAGENET1K_V2)`` (:207) fetches a checkpoint; here the weights come from a local
+    file (``--weights``) or, only on explicit request (``--synthetic-weights``), from the seeded synthetic generator.  Silently
+    writing shards of a random network would produce files that ``dataset_features.py`` accepts and ``train.py`` cannot learn from."""
+    from .weights import load_state_dict_from_path, synthetic_state_dict
+    if args.weights and args.synthetic_weights:
+        raise SystemExit("--weights and --synthetic-weights are mutually exclusive")
+    if args.weights:
+        return load_state_dict_from_path(args.weights), f"file {args.weights}"
+    if args.synthetic_weights:
+        return synthetic_state_dict(args.weights_seed), f"seeded synthetic (seed {args.weights_seed})"
+    raise SystemExit("no backbone weights: pass --weights PATH (a local torchvision ResNet-50 checkpoint, e.g. the IMAGENET1K_V2 file "
+                     "resnet50-11ad3fa6.pth the reference downloads; there is no network here) or, for benchmarks and tests only, "
+                     "--synthetic-weights")
+
+
+def weights_digest(state_dict) -> str:
+    """sha256 over the 265 float tensors the backbone consumes (names and fp32 bytes, execution order)."""
+    import hashlib
+    from .weights import iter_named_tensors
+    hsh = hashlib.sha256()
+    for name, t in iter_named_tensors(state_dict):
+        hsh.update(name.encode() + b"\0")
+        hsh.update(t.numpy().tobytes())
+    return hsh.hexdigest()
 
 
 def _resolve_device(name: str, ctx: D.RankContext) -> torch.device:
@@ -141,16 +173,17 @@ def extract_features(backbone: Callable[[torch.Tensor], torch.Tensor], variants_
     return torch.stack(per_variant, dim=1)
 
 
-def _host_payload(variants_batch, box_batch):
-    """The cheap per-clip annotations that ride to rank 0 beside the features."""
-    return {"vars": [(j3d.cpu(), j2d.cpu(), k.cpu()) for _v, j3d, j2d, k in variants_batch],
-            "box": None if box_batch is None else box_batch.cpu()}
-
-
 def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.RankContext] = None,
-                   log: Callable[[str], None] = print) -> Optional[Path]:
+                   log: Callable[[str], None] = print, host_slots: int = 4, stats: Optional[dict] = None) -> Optional[Path]:
     """Whole job for one rank.  ``backbone(x)``: (N,3,224,224) fp32 on ``device`` -> (N,2048,1,1).
-    Rank 0 packs and returns the index path; other ranks return None."""
+    Rank 0 packs and returns the index path; other ranks return None.
+
+    Round q: rank r runs global batch ``q * world + r`` (distributed.py: batches round-robin over the ranks, NOT contiguous clip
+    ranges -- every round's blocks, taken in rank order, continue the global clip order, which the shuffle pool's RNG sequence
+    needs, :98,300,345).  The loop body is: forward passes of round q -> ``post`` (pack + async gather) -> ``collect`` round q-1
+    (async D2H into a pinned slot, hand-over to the packing thread).  Nothing in it waits for the device, for a copy or for the
+    packer, so round q+1's kernels are queued while round q's features travel and round q-1's clips are packed.
+    ``stats`` (optional dict) receives ``compute_done_s`` / ``total_s`` (seconds since the loop started)."""
     ctx = ctx or D.RankContext()
     n_vars = len(AUG_NAMES) if args.augment else 1
     n_clips = len(ds)
@@ -177,11 +210,49 @@ def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.Ran
         log(f"Writing shards of {args.shard_size} clips each → {packer.out_root}")
         log("-" * 60)
 
-    t_all = t_last = time.time()
-    done = 0
+    layout = D.BlockLayout(batch=bs, n_vars=n_vars, seq_len=args.seq_len, n_joints=int(getattr(ds, "joints_num", 17)))
+    t_all = time.time()
+    progress = {"done": 0, "t_last": t_all}
+
+    def pack_round(q: int, host_blocks: torch.Tensor) -> None:
+        """Packing thread, rank 0: the ``world`` blocks of round q, in rank order == global clip order (:299-341)."""
+        for r in range(ctx.world):
+            g = q * ctx.world + r
+            clips = D.batch_clip_range(g, n_clips, bs)
+            if len(clips) == 0:
+                continue
+            blk = layout.unpack(host_blocks[r], feat_dtype, has_box=not args.augment)
+            if blk["count"] != len(clips):
+                raise RuntimeError(f"rank {r} sent {blk['count']} clips for batch {g}, expected {len(clips)}")
+            for b, ci in enumerate(clips):
+                rec = ds.index[ci]
+                group = []
+                for v in range(n_vars):
+                    group.append({
+                        "feat": blk["feats"][b, v],
+                        "joints3d": blk["joints3d"][b, v],
+                        "joints2d": blk["joints2d"][b, v],
+                        "K": blk["K"][b, v],
+                        "meta": {"subject": rec.subject, "action": rec.action, "cam": rec.cam, "start": rec.start,
+                                 "end": rec.end, "aug": AUG_NAMES[v] if args.augment else "orig",
+                                 "box": blk["box"][b] if blk["box"] is not None else None},
+                    })
+                packer.add_group(group)
+                progress["done"] += 1
+            done = progress["done"]
+            if done % 200 == 0 or done == n_clips:
+                dt = time.time() - progress["t_last"]
+                rate = 200 / dt if dt > 0 else 0.0
+                progress["t_last"] = time.time()
+                eta = (n_clips - done) / rate if rate > 0 else 0.0
+                log(f"[{100 * done / n_clips:5.1f}%] {done:6d}/{n_clips} clips | {rate:6.1f} clips/s | ETA {eta:6.1f}s | "
+                    f"shard {packer.shard_id} (pool: {len(packer.pool)} clips, carry: {len(packer.carry)} clips)")
+
+    exchange = D.RoundExchange(ctx, layout, device, pack_round, host_slots=host_slots)
     my_batches = (D.n_batches(n_clips, bs) - ctx.rank + ctx.world - 1) // ctx.world if n_clips else 0
-    for q in range(D.n_rounds(n_clips, bs, ctx.world)):
-        feats = payload = None
+    n_rounds = D.n_rounds(n_clips, bs, ctx.world)
+    for q in range(n_rounds):
+        feats = variants_batch = box_batch = None
         if q < my_batches:
             batch = next(it)
             if args.augment:
@@ -189,46 +260,19 @@ def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.Ran
             else:
                 video, j3d, j2d, k, box = batch
                 variants_batch, box_batch = [(video, j3d, j2d, k)], box
+            if variants_batch[0][0].shape[1] != args.seq_len:
+                raise RuntimeError(f"clips have {variants_batch[0][0].shape[1]} frames, --seq-len says {args.seq_len}")
             feats = extract_features(backbone, variants_batch, device, reuse_trev=not getattr(args, "no_trev_reuse", False))
-            payload = _host_payload(variants_batch, box_batch)
-            t = variants_batch[0][0].shape[1]
-        else:
-            t = args.seq_len
-        blocks = D.gather_features(ctx, feats, (bs, n_vars, t, 2048), device)
-        payloads = D.gather_objects(ctx, payload)
-        if not ctx.is_root:
-            continue
-        for r in range(ctx.world):                     # rank order == global clip order
-            g = q * ctx.world + r
-            clips = D.batch_clip_range(g, n_clips, bs)
-            if len(clips) == 0:
-                continue
-            blk, pay = blocks[r].to(feat_dtype), payloads[r]
-            if blk.shape[0] != len(clips):
-                raise RuntimeError(f"rank {r} sent {blk.shape[0]} clips for batch {g}, expected {len(clips)}")
-            for b, ci in enumerate(clips):
-                rec = ds.index[ci]
-                group = []
-                for v in range(n_vars):
-                    j3d, j2d, k = pay["vars"][v]
-                    group.append({
-                        "feat": blk[b, v],
-                        "joints3d": j3d[b],
-                        "joints2d": j2d[b],
-                        "K": k[b] if k.ndim >= 3 else k,
-                        "meta": {"subject": rec.subject, "action": rec.action, "cam": rec.cam, "start": rec.start,
-                                 "end": rec.end, "aug": AUG_NAMES[v] if args.augment else "orig",
-                                 "box": pay["box"][b] if pay["box"] is not None else None},
-                    })
-                packer.add_group(group)
-                done += 1
-            if done % 200 == 0 or done == n_clips:
-                dt = time.time() - t_last
-                rate = 200 / dt if dt > 0 else 0.0
-                t_last = time.time()
-                eta = (n_clips - done) / rate if rate > 0 else 0.0
-                log(f"[{100 * done / n_clips:5.1f}%] {done:6d}/{n_clips} clips | {rate:6.1f} clips/s | ETA {eta:6.1f}s | "
-                    f"shard {packer.shard_id} (pool: {len(packer.pool)} clips, carry: {len(packer.carry)} clips)")
+        exchange.post(q, feats, variants_batch, box_batch)
+        if q > 0:
+            exchange.collect(q - 1)
+    if n_rounds > 0:
+        exchange.collect(n_rounds - 1)
+    if stats is not None:
+        stats["compute_done_s"] = time.time() - t_all
+    exchange.finish()
+    if stats is not None:
+        stats["total_s"] = time.time() - t_all
 
     if not ctx.is_root:
         return None
@@ -249,6 +293,7 @@ def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.Ran
 @torch.no_grad()
 def main(argv: Optional[List[str]] = None) -> None:
     args = build_parser().parse_args(argv)
+    state_dict, source = _resolve_weights(args)          # fails here, before any device work, if no weight source was named
     ctx = D.init_from_env(use_gpu=True)
     device = _resolve_device(args.device, ctx)
     torch.cuda.set_device(device)
@@ -266,8 +311,17 @@ def main(argv: Optional[List[str]] = None) -> None:
     if ctx.distributed:
         torch.distributed.barrier()
     ds = _open_dataset(args)
-    backbone = ResNet50Backbone(weights_path=args.weights, seed=args.weights_seed, max_batch=args.max_batch,
-                                micro_batch=args.micro_batch, precision=args.precision).to(device).eval()
+    digest = weights_digest(state_dict)
+    log(f"Weights    : {source}  (sha256 {digest[:16]}…)")
+    if args.synthetic_weights:
+        log("WARNING    : --synthetic-weights: the backbone is a RANDOM-initialised ResNet-50; the shards will NOT hold ImageNet features")
+    backbone = ResNet50Backbone(state_dict=state_dict, max_batch=args.max_batch, micro_batch=args.micro_batch,
+                                precision=args.precision).to(device).eval()
+    if ctx.is_root:       # provenance beside the shards (index.pt keeps the reference's exact key set)
+        import json
+        Path(args.out).mkdir(parents=True, exist_ok=True)
+        (Path(args.out) / "backbone_weights.json").write_text(json.dumps(
+            {"source": source, "sha256": digest, "precision": args.precision, "synthetic": bool(args.synthetic_weights)}) + "\n")
 
     log("Warming up the HIP kernels...")                               # reference warm-up: :235-245
     warm = torch.zeros((min(args.max_batch, args.batch_size * args.seq_len), 3, 224, 224), device=device)

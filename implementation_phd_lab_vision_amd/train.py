@@ -98,6 +98,18 @@ def all_reduce_gradients(flat_grad: torch.Tensor, group=None) -> None:
     flat_grad.mul_(1.0 / world)
 
 
+def sync_overflow_flag(found: torch.Tensor, group=None) -> None:
+    """Make the skip decision of a data-parallel step GLOBAL: MAX-reduce the found-overflow flag over the ranks, so every
+    replica skips (and backs its loss scale off) or steps together.  Needed because an fp16 overflow on ONE rank is a
+    saturated 65504 -- finite -- so after the gradient all-reduce the averaged buffer is finite everywhere and only the
+    overflowing rank's own arena check fires.  The reference's ``nn.DataParallel`` has one scaler and one optimizer
+    (src/train.py:382-393) and cannot disagree with itself; this is the one-process-per-GPU equivalent."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    dist.all_reduce(found, op=dist.ReduceOp.MAX, group=group)
+
+
 class _Arena:
     """Bump allocator for the backward pass's GEMM outputs: one 16-bit buffer, so ONE overflow check covers every gradient the matrix
     cores produced in a step (and nothing is allocated per step once the first step has sized it)."""
@@ -440,6 +452,7 @@ class TrainableHead(PHDFor3DJoints):
             all_reduce_gradients(self.flat_grad, group)
             _lib.check(lib.r50_op_check_finite(self.flat_grad.data_ptr(), self.flat_grad.numel(), self._found.data_ptr(), self._stream()), None,
                        "r50_op_check_finite")
+            sync_overflow_flag(self._found, group)        # any rank overflowed -> every rank skips this step
             found = bool(self._found.item())              # the reference's scaler.step() synchronises on the same flag
             if not found:
                 optim.step(self._found)

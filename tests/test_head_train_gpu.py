@@ -262,3 +262,38 @@ def test_graphed_step_equals_eager_step(lib_built):
     g1 = (m.train_step(f, y, optim, scaler), m.flat_grad.clone())[1]
     g2 = (m.train_step(f, y, optim, scaler), m.flat_grad.clone())[1]
     assert not torch.equal(g1, g2) and bool(torch.isfinite(g2).all())
+
+
+def test_data_parallel_overflow_on_one_rank_skips_on_every_rank(lib_built, tmp_path):
+    """World size 2 (both ranks on this GPU, gloo collectives): only rank 1's gradients overflow fp16.  The found-overflow flag is
+    MAX-reduced before the decision, so both ranks skip the step together and stay bit-identical replicas."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "dp"
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(root / "tests" / "dist_train_gpu_worker.py"), str(out)], env=env, cwd=str(root),
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for rank, p in enumerate(procs):
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, f"rank {rank} failed:\n{o.decode(errors='replace')[-3000:]}"
+    r0, r1 = (torch.load(f"{out}.rank{r}", weights_only=True) for r in range(2))
+    assert r0["local_found"] == 0 and r1["local_found"] == 1          # the scenario: exactly one rank overflows locally
+    assert r0["skipped"] == r1["skipped"] and r0["skipped"][0] is True
+    assert r0["scales"] == r1["scales"] and r0["scales"][0] == 2.0 ** 11
+    assert r0["steps"] == r1["steps"]
+    assert torch.equal(r0["flat_master"], r1["flat_master"])

@@ -182,6 +182,71 @@ def test_bneck_tail_layer2_shapes(lib_built, shape):
     assert torch.equal(out, out_u), "fused block output differs from the igemm launch it replaces"
 
 
+def _tail3_inputs(n, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    y2 = _rand_bf16((n, 256, h, w), g)
+    w3 = _rand_bf16((1024, 256, 1, 1), g, scale=(2.0 / 256) ** 0.5)
+    b3 = torch.randn(1024, generator=g) * 0.1
+    idn = _rand_bf16((n, 1024, h, w), g)
+    w1 = _rand_bf16((256, 1024, 1, 1), g, scale=(2.0 / 1024) ** 0.5)
+    b1 = torch.randn(256, generator=g) * 0.1
+    return y2, w3, b3, idn, w1, b1
+
+
+@pytest.mark.parametrize("shape,bp", [((2, 7, 9), 0), ((1, 14, 14), 0), ((3, 14, 14), 112), ((3, 14, 14), 98), ((20, 14, 14), 7), ((5, 14, 14), 33)],
+                         ids=lambda v: str(v).replace(" ", ""))
+def test_bneck_tail_layer3_shapes(lib_built, shape, bp, monkeypatch):
+    """Chained layer3 tail (conv3 256->1024 + identity + ReLU, next conv1 1024->256 + ReLU; weights streamed through the LDS ring,
+    the residual as one more K-step against an identity operand, the block output handed to the second GEMM through LDS).
+    Against the oracle's two fused-op emulations, and BIT FOR BIT against the two igemm launches it replaces (same summation
+    orders).  bp = real pixels per tile: ragged tiles, several tiles per workgroup (bp 7: 560 tiles) and the batch-256 value (98)."""
+    from implementation_phd_lab_vision_amd import ops
+    from oracle.resnet50_oracle import conv_bias_act_emulated
+    n, h, w = shape
+    y2, w3, b3, idn, w1, b1 = _tail3_inputs(n, h, w, 3000 + n * h * w + bp)
+    d = _dev()
+    y2d = y2.permute(0, 2, 3, 1).contiguous().to(d)
+    idd = idn.permute(0, 2, 3, 1).contiguous().to(d)
+    w3d, w1d = w3.view(1024, 256).contiguous().to(d), w1.view(256, 1024).contiguous().to(d)
+    b3d, b1d = b3.to(d), b1.to(d)
+    if bp:
+        monkeypatch.setenv("R50_TAIL3_BP", str(bp))
+    else:
+        monkeypatch.delenv("R50_TAIL3_BP", raising=False)
+    m = n * h * w
+    guard = 4096                                   # poisoned rows behind both outputs: nothing may be stored past M
+    out_buf = torch.full((m + guard, 1024), -7.0, dtype=torch.bfloat16, device=d)
+    y1_buf = torch.full((m + guard, 256), -7.0, dtype=torch.bfloat16, device=d)
+    out, y1n = ops.bneck_tail_bf16(y2d, w3d, b3d, idd, w1d, b1d, out=out_buf[:m].view(n, h, w, 1024), y1n=y1_buf[:m].view(n, h, w, 256))
+    torch.cuda.synchronize()
+    assert bool((out_buf[m:] == -7.0).all()) and bool((y1_buf[m:] == -7.0).all()), "stored past M"
+    out_u = ops.conv2d_bf16(y2d, w3d.view(1024, 1, 1, 256), b3d, relu=True, residual=idd, tile=ops.TILE_64x128)
+    y1_u = ops.conv2d_bf16(out_u, w1d.view(256, 1, 1, 1024), b1d, relu=True, tile=ops.TILE_64x128)
+    assert torch.equal(out, out_u), "chained block output differs from the igemm launch it replaces"
+    assert torch.equal(y1n, y1_u), "chained next-conv1 output differs from the igemm launch it replaces"
+    if m <= 1000:
+        out_ref = conv_bias_act_emulated(y2.float(), w3.float(), b3, 1, 0, True, residual_bf=idn.float())
+        _check_bf16(out, out_ref, "bneck_tail3 out")
+        y1_ref = conv_bias_act_emulated(out.float().cpu().permute(0, 3, 1, 2), w1.float(), b1, 1, 0, True)
+        _check_bf16(y1n, y1_ref, "bneck_tail3 y1n")
+
+
+def test_bneck_tail_layer3_batch256_equals_unfused(lib_built, monkeypatch):
+    """The benchmarked size (256 x 14 x 14 = 50,176 pixels -> 512 tiles of 98, two per workgroup): bit-identical to the launches it replaces."""
+    from implementation_phd_lab_vision_amd import ops
+    monkeypatch.delenv("R50_TAIL3_BP", raising=False)
+    y2, w3, b3, idn, w1, b1 = _tail3_inputs(256, 14, 14, 3999)
+    d = _dev()
+    y2d = y2.permute(0, 2, 3, 1).contiguous().to(d)
+    idd = idn.permute(0, 2, 3, 1).contiguous().to(d)
+    w3d, w1d = w3.view(1024, 256).contiguous().to(d), w1.view(256, 1024).contiguous().to(d)
+    b3d, b1d = b3.to(d), b1.to(d)
+    out, y1n = ops.bneck_tail_bf16(y2d, w3d, b3d, idd, w1d, b1d)
+    out_u = ops.conv2d_bf16(y2d, w3d.view(1024, 1, 1, 256), b3d, relu=True, residual=idd)
+    y1_u = ops.conv2d_bf16(out_u, w1d.view(256, 1, 1, 1024), b1d, relu=True)
+    assert torch.equal(out, out_u) and torch.equal(y1n, y1_u)
+
+
 FP16_CASES = [CONV_CASES[i] for i in (1, 2, 3, 5, 6, 10, 12)]
 
 

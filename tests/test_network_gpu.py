@@ -410,3 +410,21 @@ def test_fp8_mode_is_batch_independent_and_needs_scales(setup_fp8):
     assert bb.layer(xs, "layer1.2").shape == (7, 56, 56, 256)
     with pytest.raises(ValueError):
         bb.set_fp8_scales([1.0] * 5)
+
+
+def test_layer3_chained_tail_is_bit_identical_to_separate_launches(setup):
+    """layer3.1-.4: conv3 + identity + ReLU chained with the next block's conv1 in one launch (bneck_tail3_kernel) -- same features,
+    bit for bit, as the two igemm launches per block it replaces; and the taps it produces match too."""
+    bb, x, *_ = setup
+    xd = x.to("cuda:0")
+    assert bb.get_option("fuse_tail3") == 1
+    fused = bb.features(xd).clone()
+    taps_f = {n: bb.layer(xd, n).clone() for n in ("layer3.1", "layer3.2.t1", "layer3.4", "layer3.5.t1", "layer3.5")}
+    bb.set_option("fuse_tail3", 0)
+    try:
+        plain = bb.features(xd).clone()
+        for n, t in taps_f.items():
+            assert torch.equal(t, bb.layer(xd, n)), n
+    finally:
+        bb.set_option("fuse_tail3", 1)
+    assert torch.equal(fused, plain)
