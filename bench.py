@@ -366,10 +366,16 @@ def main() -> None:
                                          "bound": "hbm", "achieved": t_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": t_ach / HBM_PEAK_GBPS,
                                          "traffic": t_traffic, "avg_launch_us": 1e3 * tl["ms"] / max(1, tl["launches"]),
                                          "bytes_per_launch": tl["bytes"] / max(1, tl["launches"])}
-        classes = ("igemm", "bneck_tail", "conv1", "maxpool", "avgpool", "stem_pack")
-        tot_ms = sum(prof[k]["ms"] for k in classes)
+        t3 = prof.get("bneck_tail3")
+        if t3 and t3["ms"] > 0:       # the chained layer3 tails (conv3 + identity + ReLU + next conv1): both MFMA work and HBM streaming
+            roofline["third_kernel"] = {"kernel": "bneck_tail3_kernel (%d launches/step)" % round(t3["launches"] / max(1, args.steps)),
+                                        "avg_launch_us": 1e3 * t3["ms"] / max(1, t3["launches"]),
+                                        "tflops": t3["flops"] / (t3["ms"] * 1e-3) / 1e12, "frac_of_mfma_peak": t3["flops"] / (t3["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                        "GBps": t3["bytes"] / (t3["ms"] * 1e-3) / 1e9, "frac_of_hbm_peak": t3["bytes"] / (t3["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        classes = ("igemm", "bneck_tail", "bneck_tail3", "conv1", "maxpool", "avgpool", "stem_pack")
+        tot_ms = sum(prof[k]["ms"] for k in classes if k in prof)
         kernels = {k: {"launches_per_step": prof[k]["launches"] / args.steps, "ms_per_step": prof[k]["ms"] / args.steps,
-                       "share": prof[k]["ms"] / tot_ms if tot_ms else 0.0} for k in classes if prof[k]["launches"]}
+                       "share": prof[k]["ms"] / tot_ms if tot_ms else 0.0} for k in classes if k in prof and prof[k]["launches"]}
         kernels["stages_ms_per_step"] = {f"layer{i}": sum(v["ms"] for n_, v in prof.items() if n_.startswith(f"layer{i}.")) / args.steps
                                          for i in (1, 2, 3, 4)}
 

@@ -1353,213 +1353,247 @@ __global__ __launch_bounds__(512) void bneck_tail2_kernel(const Tail2Args a) {
 // identity)` of block b, `relu(bn1(conv1(x)))` of block b+1).
 // Why: at 14x14 both convs are HBM-phase / MFMA-phase alternators (conv3: 59 us at 3.9 TB/s, conv1: 37 us at 3.4 TB/s, batch 256).
 // Chained, the 103 MB block output is written once and never read back by conv1, and one launch boundary disappears.
-// The weights (2 x 512 KB) do not fit LDS or registers, so -- unlike the layer1 / layer2 tails -- they STREAM through an LDS ring
-// filled by loader waves (the igemm_ws_kernel scheme), and the chain runs over 128-channel CHUNKS c of the block output:
-//     A(c):  accA[128 x P] = b3[c] + W3[c] . t2          4 K-steps of 64; the pixel tile's t2 rows stay RESIDENT in LDS for the tile
-//     I(c):  accA += res[c]                              the residual rows arrive by loader DMA like any operand (no vector-memory load
-//            in the consumer waves); each lane reads its 8 channels back from LDS and adds them with the very fp32 additions of the
-//            igemm epilogue (an MFMA against an identity operand would be cheaper, but its accumulate differs from fl(a + b) in ~1e-7
-//            of the elements)
-//     E(c):  relu, 16-bit, -> HBM (block output) and -> LDS as the B operand `out_c` (P rows x 256 B)
+// The chain runs over 128-channel CHUNKS c of the block output, for a tile of P pixels:
+//     A(c):  accA[128 x P] = b3[c] + W3[c] . t2          4 K-slots of 64; the tile's t2 rows are RESIDENT in LDS
+//     E(c):  accA += res[c]; relu; 16-bit -> LDS `out_c` (P rows x 256 B): the block output AND the B operand of the second GEMM
 //     B(c):  accB[256 x P] += W1[:, c] . out_c           2 K-slots x 2 cout halves; accB stays in registers across the 8 chunks
-// and, after chunk 7, y1n = relu(accB) (accB started at b1).  Summation orders are those of the igemm launches this replaces
-// (bias first, K ascending, residual last), so both outputs are bit-identical to them.
-// Geometry: P = 112 pixel rows in LDS (7 MFMA column blocks), of which the first `bp` are real (bp = 98 at batch 256: 512 tiles =
-// two full rounds of 256 CUs); 4 consumer waves (wave w: couts 32w.. of a 128-row W slice; all 112 pixels) + 4 loader waves.
-// A CU takes in at most ~40 B/clk from L2, so what is staged per MFMA cycle decides the speed: every ring stage is 16 KB = 4 LDS-DMA
-// instructions per loader wave against 28 MFMAs per consumer wave:
-//     T step (4 per tile): t2 rows, K-slot k -> the resident T2 region        A step: W3 slice [128 rows x 64 K]
-//     I step (2 per chunk): residual rows, slot s (waves 2s, 2s+1 consume)     B step: W1 slice [128 rows (half h) x 64 K (slot kb)]
-// (rows of 128 B, 16-B chunk c of row r at chunk c ^ (r & 7), as in the igemm kernels).  LDS: ring 4 x 16 KB (3 stages in flight) +
-// T2 4 x 14 KB + out_c 2 x 14 KB + b1, b3 = 156,672 B.  4 + 8 x 10 = 84 steps (barriers) per tile.
+// and, after chunk 7, y1n = relu(accB) (accB started at b1).  Summation orders are those of the igemm launches this replaces (bias
+// first, K ascending, residual last, the residual added with the same fp32 additions), so both outputs are bit-identical to them.
+// Three roles (what two earlier versions taught: with weights and activations both streaming through one LDS ring under a barrier
+// per K-step, ring issue, L2 latency, fragment reads, MFMAs, epilogue and stores simply ADD UP -- 84 us for 2 x 14.5 us of MFMA):
+//   * 4 CONSUMER waves (wave w: couts 32w.. of every 128-row weight slice, all P = 112 pixel columns = 7 MFMA blocks).  A wave's
+//     weight fragments are private to it, so they do not go through LDS at all: the host-side packing (tail3_pack_kernel) stores every
+//     (chunk, step, wave) slice in MFMA fragment order and the wave fetches it with four fully coalesced 1-KB loads, two steps ahead
+//     into the registers the previous step has just released.  The 64 weight steps of a tile need NO barrier.  Consumers touch
+//     vector memory only for those loads (and the tile's y1n stores): no store ever sits in front of a load in their in-order queue.
+//   * 4 HELPER waves: LDS-DMA of the tile's t2 rows (once per tile) and of each chunk's residual rows (two chunks ahead, double
+//     buffered), and the COPY-OUT of out_c to the block output in HBM with full-row 16-B stores.
+//   * 2 barriers per chunk -- R(c): residual(c) has landed / everybody is done with out_c(c-1); O(c): out_c(c) is complete / res
+//     buffer c&1 is free -- and one per tile (T: t2 rows landed).  17 per tile.
+// P = 112 rows in LDS of which the first `bp` are real (bp = 98 at batch 256: 512 tiles = two full rounds of 256 CUs).
+// LDS (rows of 128 B, 16-B chunk c of row r at chunk c ^ (r & 7) as in the igemm kernels): T2 [4 slots][112] 56 KB, res 2 x [2][112]
+// 56 KB, out_c [2][112] 28 KB, b1 + b3 5 KB = 148,480 B.
 // ------------------------------------------------------------------------------------------------
 struct Tail3Args {
     const __bf16* y2;     // (M, 256)   conv2 output
-    const __bf16* w3;     // (1024, 256) folded conv3 weights, K contiguous
+    const __bf16* wp;     // packed weights of both convs: [chunk 8][step 8: W3 K-slot 0..3, then W1 (K-slot kb, cout half h) = 2 kb + h][wave 4]
+                          // [fragment 4 = 2 m + kk][lane 64] x 16 B  (tail3_pack_kernel), 1 MB
     const float* b3;      // (1024)
     const __bf16* res;    // (M, 1024)  identity
     __bf16* out;          // (M, 1024)  block output
-    const __bf16* w1;     // (256, 1024) folded weights of the next block's conv1
     const float* b1;      // (256)
     __bf16* y1n;          // (M, 256)   next block's conv1 output
     int M;
     int bp;               // real pixels per tile (<= 112)
     int n_tiles;          // ceil(M / bp)
+#if defined(R50_STAMP)    // diagnostic build (scripts/stamp_tail3.py): per-wave cycle sums, 8 slots per wave
+    unsigned long long* dbg;
+#endif
 };
 
+// (1024,256) conv3 and (256,1024) next-conv1 weights, K contiguous -> the fragment-ordered stream bneck_tail3_kernel reads.
+// Element (c, s, w, f = 2m + kk, lane = 16 fq + fr) is the A fragment of row rho = 32w + 16m + fr of the step's 128-row slice, whose
+// channel is perm(rho) (8 consecutive couts per lane, see igemm_bf16_kernel), K = 32 kk + 8 fq .. + 7 of the step's 64.
+__global__ void tail3_pack_kernel(const __bf16* __restrict__ w3, const __bf16* __restrict__ w1, __bf16* __restrict__ wp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // one 16-B element each; 8 * 8 * 4 * 4 * 64 = 65,536
+    if (idx >= 65536) return;
+    const int lane = idx & 63, f = (idx >> 6) & 3, w = (idx >> 8) & 3, st = (idx >> 10) & 7, c = idx >> 13;
+    const int fr = lane & 15, fq = lane >> 4, m = f >> 1, kk = f & 1;
+    const int rho = 32 * w + 16 * m + fr;
+    const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+    const __bf16* src;
+    if (st < 4) src = w3 + (size_t)(c * 128 + cl) * 256 + st * 64 + kk * 32 + fq * 8;
+    else {
+        const int bs = st - 4, kb = bs >> 1, hh = bs & 1;
+        src = w1 + (size_t)(hh * 128 + cl) * 1024 + c * 128 + kb * 64 + kk * 32 + fq * 8;
+    }
+    reinterpret_cast<u32x4*>(wp)[idx] = *reinterpret_cast<const u32x4*>(src);
+}
+
+// Diagnostic ablations of bneck_tail3_kernel (scripts/build_variant.sh -DT3_ABL=mask; timing only, results are wrong):
+// 1 = every LDS-DMA zero-fills (no L2 traffic for t2 / residual), 2 = no HBM stores, 4 = no MFMAs (fragment reads stay),
+// 8 = no residual / epilogue work, 16 = no weight loads
+#ifndef T3_ABL
+#define T3_ABL 0
+#endif
+#ifndef T3_PDA            // LDS prefetch depth (fragment slots) of the A / B weight steps
+#define T3_PDA 4
+#endif
+#ifndef T3_PDB
+#define T3_PDB 7
+#endif
 template <int ET>
 __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int CMID = 256, COUT = 1024, C1N = 256;
     constexpr int NCH = COUT / 128;               // chunks of 128 block-output channels
-    constexpr int KA = CMID / 64;                 // K-slots of t2 = T steps per tile = A steps per chunk
-    constexpr int SPC = KA + 2 + 4;               // steps per chunk: A x4, I x2, B x4
-    constexpr int SPT = KA + NCH * SPC;           // steps per tile
     constexpr int PR = 112, NR = 7;               // pixel rows held in LDS / MFMA column blocks
-    constexpr int STAGE = 16384, NSTAGE = 4, D = NSTAGE - 1, LPS = 4;    // LDS-DMA instructions per loader wave per stage
-    constexpr int T2 = NSTAGE * STAGE;            // resident t2 tile: 4 K-slots of 128 rows (112 + 16 pad rows the DMA zero-fills)
-    constexpr int T2_SLOT = PR * 128;             // 14 KB: the 4th DMA pass of loader waves 2, 3 (rows 112..127) is redirected, see below
-    constexpr int OUTC = T2 + KA * T2_SLOT, OUTC_SLOT = PR * 128;
-    constexpr int B1_OFF = OUTC + 2 * OUTC_SLOT, B3_OFF = B1_OFF + C1N * 4;
+    constexpr int SLOT = PR * 128;                // one K-slot (64 channels) of PR pixel rows: 14 KB
+    constexpr int T2 = 0, RES = 4 * SLOT, OUTC = RES + 4 * SLOT, B1_OFF = OUTC + 2 * SLOT, B3_OFF = B1_OFF + C1N * 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grid = gridDim.x;
     const int first = blockIdx.x;
-    const int my_tiles = (a.n_tiles - first + grid - 1) / grid;
-    const int total = my_tiles * SPT;
 
-    if (tid < C1N) {                              // both bias vectors live in LDS: no bias registers, no vector-memory loads in the consumers
+    if (tid < C1N) {                              // both bias vectors live in LDS
         reinterpret_cast<float*>(smem + B1_OFF)[tid] = a.b1[tid];
         reinterpret_cast<f32x4*>(smem + B3_OFF)[tid] = reinterpret_cast<const f32x4*>(a.b3)[tid];
     }
 
     if (wave >= 4) {
-        // =============================== loader waves ===============================================
+        // =============================== helper waves: DMA in, copy out ==============================
         const int lw = wave - 4;
         const int lt = tid - 256;
-        const int srow = lt >> 3, slot = lt & 7;
-        const int lchunk = slot ^ (srow & 7);
-        const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w3), 0, COUT * CMID * 2u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w1), 0, C1N * COUT * 2u, 0x00020000);
+        const int srow = lt >> 3;                  // 0..31: row of a 32-row pass
         const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.y2), 0, (unsigned)a.M * (CMID * 2u), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.M * (COUT * 2u), 0x00020000);
-        unsigned w3_voff[4], w1_voff[4], y2_voff[4], res_voff[4];
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.M * (COUT * 2u), 0x00020000);
+        // row R = 32 i + srow of a [slots][112]-row region: K-slot R / 112, pixel row R % 112; logical 16-B chunk (lane & 7) ^ (pixel row & 7)
+        // byte offset of the lane's 16 B inside its pixel's channel vector (+ pixel * channels * 2), or out of range
+        auto row_voff = [&](int i, int p0, int limit, int cstride) -> unsigned {
+            const int R = 32 * i + srow;
+            const int sl = (R >= 336) ? 3 : (R >= 224) ? 2 : (R >= 112) ? 1 : 0;
+            const int prow = R - 112 * sl;
+            const int lchunk = (lt & 7) ^ (prow & 7);
+            return (prow < limit && !(T3_ABL & 1)) ? (unsigned)((p0 + prow) * cstride + sl * 64 + lchunk * 8) * 2u : kOobOffset;
+        };
+        auto issue_t2 = [&](int tile) {           // 14 DMAs per wave: the tile's t2 rows, 4 K-slots
+            const int p0 = tile * a.bp;
+            const int limit = (tile < a.n_tiles) ? ((a.M - p0 < a.bp) ? a.M - p0 : a.bp) : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {             // LDS row rho holds channel perm(rho) of its 32-row group (8 consecutive couts per lane)
-            const int rho = i * 32 + srow;
-            const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
-            w1_voff[i] = (unsigned)(cl * COUT + lchunk * 8) * 2u;
-            w3_voff[i] = (unsigned)(cl * CMID + lchunk * 8) * 2u;
-        }
-        auto decode_tile = [&](int tile) {
+            for (int i = 0; i < 14; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y2, (LDS_AS void*)(smem + T2 + i * 4096 + lw * 1024), 16, row_voff(i, p0, limit, CMID), 0, 0, 0);
+        };
+        auto issue_res = [&](int tile, int c) {   // 7 DMAs per wave: residual rows of chunk c (2 K-slots) into buffer c & 1
+            const int p0 = tile * a.bp;
+            const int limit = (tile < a.n_tiles) ? ((a.M - p0 < a.bp) ? a.M - p0 : a.bp) : 0;
+            const int cofs = __builtin_amdgcn_readfirstlane(c * 256);
+            char* dst = smem + RES + (c & 1) * 2 * SLOT + lw * 1024;
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(dst + i * 4096), 16, row_voff(i, p0, limit, COUT), cofs, 0, 0);
+        };
+        auto copy_out = [&](int tile, int c) {    // 7 x (16 B from out_c -> block output): full 128-B row pieces
             const int p0 = tile * a.bp;
             const int limit = (a.M - p0 < a.bp) ? a.M - p0 : a.bp;
+            const int cofs = __builtin_amdgcn_readfirstlane(c * 256);
+            u32x4 v[7];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int prow = i * 32 + srow;
-                const bool ok = prow < limit;          // rows past the tile's pixels (and the 16 pad rows) read as zeros
-                y2_voff[i] = ok ? (unsigned)((p0 + prow) * CMID + lchunk * 8) * 2u : kOobOffset;
-                res_voff[i] = ok ? (unsigned)((p0 + prow) * COUT + lchunk * 8) * 2u : kOobOffset;
-            }
-        };
-        int i_tile = first, i_c = -1, i_s = 0, i_buf = 0;      // i_c == -1: the tile's T steps
-        decode_tile(i_tile);
-        auto stage_issue = [&]() {
-            char* sbase = smem + i_buf * STAGE + lw * 1024;
-            if (i_c < 0) {                                                     // T: t2 rows, K-slot i_s -> resident region
-                // slots are 112 rows: the last pass of loader waves 2, 3 would write rows 112..127 = the next slot, so it goes (as a
-                // zero fill: those rows are always out of range) to this step's ring stage, which a T step does not use.  Every wave
-                // still issues LPS instructions per step: the counted vmcnt waits depend on it.
-                char* tb = smem + T2 + i_s * T2_SLOT + lw * 1024;
-                const int xofs = __builtin_amdgcn_readfirstlane(i_s * 128);
+            for (int i = 0; i < 7; ++i) v[i] = *reinterpret_cast<const u32x4*>(smem + OUTC + i * 4096 + lt * 16);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y2, (LDS_AS void*)((i == 3 && lw >= 2) ? sbase : tb + i * 4096), 16, y2_voff[i], xofs, 0, 0);
-            } else if (i_s < KA) {                                             // A: W3 rows of chunk i_c, K-slot i_s
-                const int wofs = __builtin_amdgcn_readfirstlane(i_c * (128 * CMID * 2) + i_s * 128);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (LDS_AS void*)(sbase + i * 4096), 16, w3_voff[i], wofs, 0, 0);
-            } else if (i_s < KA + 2) {                                         // I: residual rows, channels 128 i_c + 64 s ..
-                const int rofs = __builtin_amdgcn_readfirstlane(i_c * 256 + (i_s - KA) * 128);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(sbase + i * 4096), 16, res_voff[i], rofs, 0, 0);
-            } else {                                                           // B: W1 rows 128 h .., K = 128 i_c + 64 kb ..
-                const int bs = i_s - KA - 2, kb = bs >> 1, hh = bs & 1;
-                const int wofs = __builtin_amdgcn_readfirstlane(hh * (128 * COUT * 2) + i_c * 256 + kb * 128);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (LDS_AS void*)(sbase + i * 4096), 16, w1_voff[i], wofs, 0, 0);
-            }
-            i_buf = (i_buf + 1) & (NSTAGE - 1);
-            ++i_s;
-            if (i_c < 0) {
-                if (i_s == KA) { i_s = 0; i_c = 0; }
-            } else if (i_s == SPC) {
-                i_s = 0;
-                if (++i_c == NCH) {
-                    i_c = -1;
-                    i_tile += grid;
-                    if (i_tile < a.n_tiles) decode_tile(i_tile);
+            for (int i = 0; i < 7; ++i) {
+                unsigned voff = row_voff(i, p0, limit, COUT);
+                if (T3_ABL & 1) {                  // (ablation 1 makes row_voff out of range: rebuild the store offset)
+                    const int R = 32 * i + srow, sl = (R >= 112) ? 1 : 0, prow = R - 112 * sl;
+                    voff = (prow < limit) ? (unsigned)((p0 + prow) * COUT + sl * 64 + (((lt & 7) ^ (prow & 7)) * 8)) * 2u : kOobOffset;
                 }
+                if (!(T3_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, voff, cofs, 0);
             }
         };
-#pragma unroll
-        for (int s = 0; s < D; ++s) stage_issue();           // total is a multiple of 84 (>= D)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPS) : "memory");      // step 0 landed
-        __builtin_amdgcn_s_barrier();             // pairs with the consumers' first barrier
-        for (int g = 0; g < total; ++g) {
-            if (g + D < total) stage_issue();
-            // steps issued so far: 0 .. min(g+D, total-1); step g+1 must be complete before the barrier ending step g
-            if (g + D < total) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPS) : "memory");
-            } else if (g + D - 1 < total) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * LPS) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+        // Every wave's vector-memory queue holds, in issue order:  ... Res(t,0) | stores(6) | T2(t) | Res(t,1) | stores(7) |   <- previous tile
+        //    Res(t,2) | stores(0) | Res(t,3) | stores(1) | ...   with 7 / 14 operations per group (requests for tiles past the end are
+        // issued too, as zero fills, so the counts never change).  The first tile has no stores in front: prologue = Res(0) | T2 | Res(1).
+        issue_res(first, 0);
+        issue_t2(first);
+        issue_res(first, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // biases staged (pairs with the consumers' first barrier)
+        bool first_tile = true;
+        R50_STAMP_DECL
+        for (int tile = first; tile < a.n_tiles; tile += grid) {
+            // T: t2 rows landed.  Younger than T2(t): Res(t,1) [+ stores(7)]
+            if (first_tile) { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
             __builtin_amdgcn_s_barrier();
+            for (int c = 0; c < NCH; ++c) {
+                // R(c): residual(c) landed.  Younger than Res(t,c): see the queue above
+                if (c == 0) {
+                    if (first_tile) { asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); }
+                } else if (c == 1) {
+                    if (first_tile) { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); }
+                } else {
+                    asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+                }
+                R50_MARK(0)                       // wait: residual landed
+                __builtin_amdgcn_s_barrier();
+                R50_MARK(1)                       // barrier R
+                if (c == NCH - 1) issue_t2(tile + grid);        // every consumer is past A(7): the T2 region is free
+                __builtin_amdgcn_s_barrier();     // O(c): out_c(c) complete, res buffer c & 1 free
+                R50_MARK(2)                       // (t2 issue +) barrier O
+                if (c + 2 < NCH) issue_res(tile, c + 2); else issue_res(tile + grid, c + 2 - NCH);
+                R50_MARK(3)                       // residual DMA issue
+                copy_out(tile, c);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the copy's LDS reads are complete before this wave arrives at R(c+1))
+                R50_MARK(4)                       // copy-out: LDS reads + store issue
+            }
+            first_tile = false;
         }
+        R50_STAMP_FLUSH(8)
     } else {
         // =============================== consumer waves =============================================
         const int w = wave;
         const int fr = lane & 15, fq = lane >> 4;
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.M * (COUT * 2u), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.M * (C1N * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wp), 0, 1048576u, 0x00020000);
+        const unsigned wp_voff = (unsigned)(lane * 16 + w * 4096);
         const int fphys0 = (fq ^ (fr & 7)) << 4;                       // kk = 0; kk = 1 is ^ 64
-        const int w_frag = (32 * w + fr) * 128;                         // + m*2048: this wave's 32 rows of a 128-row W slice
         const int x_frag = fr * 128;                                    // + j*2048
-        // the wave's channels 32w .. 32w+31 of a chunk: slot w>>1, 16-B chunks 4(w&1) + fq of a pixel row (residual in, out_c out)
-        const int c_frag = x_frag + (((4 * (w & 1) + fq) ^ (fr & 7)) << 4);
+        // the wave's channels 32w .. 32w+31 of a chunk: slot w>>1, 16-B chunk 4(w&1) + fq of a pixel row (residual in, out_c out)
+        const int c_frag = (w >> 1) * SLOT + x_frag + (((4 * (w & 1) + fq) ^ (fr & 7)) << 4);
         f32x4 accA[2][NR], accB[4][NR];
-        // one W-slice step: acc[m][j] += W[32w + 16m ..][64 K] . X[64 K][16 j ..]; a single set of pixel fragments (the kernel sits at the
-        // 256-register limit): the K = 32..63 fragment of pixel block j replaces the K = 0..31 one as soon as that block's MFMAs are
-        // issued and is consumed 14 MFMAs later (order pinned with sched_group_barrier)
-        auto w_step = [&](const char* wb, const char* xb, f32x4 (&acc0)[NR], f32x4 (&acc1)[NR]) {
-            bf16x8 x[NR], w0[2], w1[2];
+        bf16x8 wA[4], wB[4];
+        auto w_load = [&](int gs, bf16x8 (&wf)[4]) {     // weight fragments of step gs (0..63 of a tile; the stream is the same for every tile)
+            const int sofs = __builtin_amdgcn_readfirstlane((gs & 63) * 16384);
 #pragma unroll
-            for (int j = 0; j < NR; ++j) x[j] = *reinterpret_cast<const bf16x8*>(xb + x_frag + j * 2048 + fphys0);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) w0[m] = *reinterpret_cast<const bf16x8*>(wb + w_frag + m * 2048 + fphys0);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) w1[m] = *reinterpret_cast<const bf16x8*>(wb + w_frag + m * 2048 + (fphys0 ^ 64));
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                acc0[j] = mfma_e<ET>(w0[0], x[j], acc0[j]);
-                acc1[j] = mfma_e<ET>(w0[1], x[j], acc1[j]);
-                x[j] = *reinterpret_cast<const bf16x8*>(xb + x_frag + j * 2048 + (fphys0 ^ 64));
+            for (int f = 0; f < 4; ++f) {
+                if constexpr (T3_ABL & 16) wf[f] = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)gs, 1u, 2u, 3u});
+                else wf[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wp, wp_voff + f * 1024, sofs, 0));
             }
+        };
+        // one weight step: acc[m][j] += W[32w + 16m ..][64 K] . X[64 K][16 j ..].  A single set of pixel fragments (the kernel sits at
+        // the 256-register limit): the K = 32..63 fragment of pixel block j replaces the K = 0..31 one as soon as that block's MFMAs
+        // are issued and is consumed 14 MFMAs later; then the fragments of step gs + 2 are requested into the registers this step
+        // has released (order pinned with sched_group_barrier).
+        auto w_step = [&](auto pd, int gs, bf16x8 (&wf)[4], const char* xb, f32x4 (&acc0)[NR], f32x4 (&acc1)[NR]) {
+            // 14 slots t = 7 kk + j, each one pixel fragment and two MFMAs; the fragment of slot t + PD is read when slot t issues.
+            // One wave per SIMD sees ~190 cycles of LDS latency under this load, i.e. 6 slots; the A steps (accA and accB both live)
+            // have registers for PD = 4, the B steps (accA dead) for 7.
+            constexpr int NS = 2 * NR, PD = decltype(pd)::value;
+            bf16x8 x[NS];
+            auto xread = [&](int t) { return *reinterpret_cast<const bf16x8*>(xb + x_frag + (t % NR) * 2048 + (t >= NR ? (fphys0 ^ 64) : fphys0)); };
 #pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                acc0[j] = mfma_e<ET>(w1[0], x[j], acc0[j]);
-                acc1[j] = mfma_e<ET>(w1[1], x[j], acc1[j]);
+            for (int t = 0; t < PD; ++t) x[t] = xread(t);
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                const int j = t % NR, kk = t / NR;
+                if constexpr (T3_ABL & 4) { asm volatile("" ::"v"(wf[kk]), "v"(wf[2 + kk]), "v"(x[t])); }
+                else {
+                acc0[j] = mfma_e<ET>(wf[kk], x[t], acc0[j]);
+                acc1[j] = mfma_e<ET>(wf[2 + kk], x[t], acc1[j]);
+                }
+                if (t + PD < NS) x[t + PD] = xread(t + PD);
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, NR + 4, 0);
+            w_load(gs + 2, wf);
+            __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
 #pragma unroll
-            for (int j = 0; j < NR; ++j) {
+            for (int t = 0; t < NS - PD; ++t) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NR, 0);
-            // the barrier stays BEHIND the step's last MFMA, i.e. behind the lgkmcnt(0) that MFMA needs: every fragment read of this
-            // stage has returned before the loaders may refill it (hoisted above the MFMAs, reads could still be in flight)
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * PD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
         };
-        int c_buf = 0;
+        w_load(0, wA);
+        w_load(1, wB);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's part of the biases is in LDS ...
-        __builtin_amdgcn_s_barrier();             // ... and after the barrier everybody's; step 0 landed
+        __builtin_amdgcn_s_barrier();             // ... and after the barrier everybody's
+        R50_STAMP_DECL
         for (int tile = first; tile < a.n_tiles; tile += grid) {
             const int p0 = tile * a.bp;
             const int limit = (a.M - p0 < a.bp) ? a.M - p0 : a.bp;
-#pragma unroll
-            for (int k = 0; k < KA; ++k) {        // T steps: the loaders bring the tile's t2 rows in; nothing to compute
-                c_buf = (c_buf + 1) & (NSTAGE - 1);
-                __builtin_amdgcn_s_barrier();
-            }
+            __builtin_amdgcn_s_barrier();         // T: the tile's t2 rows are in LDS
+            R50_MARK(0)                           // barrier T (+ previous tile's y1n stores)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {         // accB[2t + e]: channels 128t + 32w + 8fq + 4e ..
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + B1_OFF + (128 * t + 32 * w + 8 * fq) * 4);
@@ -1574,51 +1608,54 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
 #pragma unroll
                     for (int j = 0; j < NR; ++j) { accA[0][j] = lo; accA[1][j] = hi; }
                 }
-                // ---- A: 4 K-slots of W3[c] . t2
-                for (int k = 0; k < KA; ++k) {
-                    w_step(smem + c_buf * STAGE, smem + T2 + k * T2_SLOT, accA[0], accA[1]);
-                    c_buf = (c_buf + 1) & (NSTAGE - 1);
-                }
-                // ---- I: + identity (waves 2s, 2s+1 in step s), then E: ReLU, 16-bit, to HBM and to LDS (B operand of the second GEMM)
+                // ---- A: 4 K-slots of W3[c] . t2 (no barriers: weights from this wave's registers, t2 resident)
+                w_step(std::integral_constant<int, T3_PDA>{}, c * 8 + 0, wA, smem + T2 + 0 * SLOT, accA[0], accA[1]);
+                w_step(std::integral_constant<int, T3_PDA>{}, c * 8 + 1, wB, smem + T2 + 1 * SLOT, accA[0], accA[1]);
+                w_step(std::integral_constant<int, T3_PDA>{}, c * 8 + 2, wA, smem + T2 + 2 * SLOT, accA[0], accA[1]);
+                w_step(std::integral_constant<int, T3_PDA>{}, c * 8 + 3, wB, smem + T2 + 3 * SLOT, accA[0], accA[1]);
+#if defined(R50_STAMP)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 0" ::"v"(accA[1][NR - 1]), "v"(accA[0][NR - 1]) : "memory");   // the stamp waits for the last MFMAs
+#endif
+                R50_MARK(1)                       // A: 4 weight steps
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();     // R(c): residual(c) is in LDS; everybody (helpers too) is done with out_c(c-1)
+                R50_MARK(2)                       // barrier R
+                // ---- E: + identity, ReLU, 16-bit -> out_c
+                if (!(T3_ABL & 8)) {
+                    const char* rb = smem + RES + (c & 1) * 2 * SLOT + c_frag;
+                    u32x4 r[NR];
 #pragma unroll
-                for (int sI = 0; sI < 2; ++sI) {
-                    if (sI == (w >> 1)) {
-                        const char* sb = smem + c_buf * STAGE;
-                        u32x4 r[NR];
+                    for (int j = 0; j < NR; ++j) r[j] = *reinterpret_cast<const u32x4*>(rb + j * 2048);
 #pragma unroll
-                        for (int j = 0; j < NR; ++j) r[j] = *reinterpret_cast<const u32x4*>(sb + c_frag + j * 2048);
-                        const int cofs = __builtin_amdgcn_readfirstlane(c * 256);
-                        // store offsets are recomputed per chunk from an opaque copy of the lane's pixel: hoisted out of the chunk loop they
-                        // would pin 7 more registers for the whole tile
-                        int pix = fr;
-                        asm volatile("" : "+v"(pix));
+                    for (int j = 0; j < NR; ++j) {
+                        f32x4 lo = accA[0][j], hi = accA[1][j];
+                        lo[0] += unpack_lo_e<ET>(r[j][0]); lo[1] += unpack_hi_e<ET>(r[j][0]);
+                        lo[2] += unpack_lo_e<ET>(r[j][1]); lo[3] += unpack_hi_e<ET>(r[j][1]);
+                        hi[0] += unpack_lo_e<ET>(r[j][2]); hi[1] += unpack_hi_e<ET>(r[j][2]);
+                        hi[2] += unpack_lo_e<ET>(r[j][3]); hi[3] += unpack_hi_e<ET>(r[j][3]);
+                        u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
 #pragma unroll
-                        for (int j = 0; j < NR; ++j) {
-                            f32x4 lo = accA[0][j], hi = accA[1][j];
-                            lo[0] += unpack_lo_e<ET>(r[j][0]); lo[1] += unpack_hi_e<ET>(r[j][0]);
-                            lo[2] += unpack_lo_e<ET>(r[j][1]); lo[3] += unpack_hi_e<ET>(r[j][1]);
-                            hi[0] += unpack_lo_e<ET>(r[j][2]); hi[1] += unpack_hi_e<ET>(r[j][2]);
-                            hi[2] += unpack_lo_e<ET>(r[j][3]); hi[3] += unpack_hi_e<ET>(r[j][3]);
-                            u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
-                            *reinterpret_cast<u32x4*>(smem + OUTC + (w >> 1) * OUTC_SLOT + c_frag + j * 2048) = o;
-                            const unsigned voff = (16 * j + pix < limit) ? (unsigned)((p0 + 16 * j + pix) * COUT + 32 * w + 8 * fq) * 2u : kOobOffset;
-                            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, voff, cofs, 0);
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // out_c written before anybody reads it
+                        for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                        *reinterpret_cast<u32x4*>(smem + OUTC + c_frag + j * 2048) = o;
                     }
-                    c_buf = (c_buf + 1) & (NSTAGE - 1);
-                    __builtin_amdgcn_s_barrier();
                 }
-                // ---- B: W1[:, c] . out_c, K-slot kb x cout half h
-#pragma unroll
-                for (int bs = 0; bs < 4; ++bs) {
-                    w_step(smem + c_buf * STAGE, smem + OUTC + (bs >> 1) * OUTC_SLOT, accB[2 * (bs & 1)], accB[2 * (bs & 1) + 1]);
-                    c_buf = (c_buf + 1) & (NSTAGE - 1);
-                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // out_c written before anybody reads it
+                R50_MARK(3)                       // E
+                __builtin_amdgcn_s_barrier();     // O(c)
+                R50_MARK(4)                       // barrier O
+                // ---- B: W1[:, c] . out_c, K-slot kb x cout half h (no barriers)
+                w_step(std::integral_constant<int, T3_PDB>{}, c * 8 + 4, wA, smem + OUTC + 0 * SLOT, accB[0], accB[1]);
+                w_step(std::integral_constant<int, T3_PDB>{}, c * 8 + 5, wB, smem + OUTC + 0 * SLOT, accB[2], accB[3]);
+                w_step(std::integral_constant<int, T3_PDB>{}, c * 8 + 6, wA, smem + OUTC + 1 * SLOT, accB[0], accB[1]);
+                w_step(std::integral_constant<int, T3_PDB>{}, c * 8 + 7, wB, smem + OUTC + 1 * SLOT, accB[2], accB[3]);
+#if defined(R50_STAMP)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 0" ::"v"(accB[3][NR - 1]), "v"(accB[2][NR - 1]), "v"(accB[1][NR - 1]), "v"(accB[0][NR - 1]) : "memory");
+#endif
+                R50_MARK(5)                       // B: 4 weight steps
             }
-            // ---- next conv1's output: ReLU, 16-bit, 16-B stores
+            // ---- next conv1's output: ReLU, 16-bit, 16-B stores (the next tile's first two weight steps are already requested)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1628,9 +1665,11 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
                     const unsigned voff = (16 * j + fr < limit) ? (unsigned)((p0 + 16 * j + fr) * C1N + 128 * t + 32 * w + 8 * fq) * 2u : kOobOffset;
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, voff, 0, 0);
+                    if (!(T3_ABL & 2) || o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, voff, 0, 0);
                 }
+            R50_MARK(6)                           // y1n epilogue
         }
+        R50_STAMP_FLUSH(8)
     }
 #else
     (void)a;

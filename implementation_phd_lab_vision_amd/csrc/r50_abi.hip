@@ -67,6 +67,7 @@ struct r50_handle {
     float* cat_bias[4] = {nullptr, nullptr, nullptr, nullptr};    // b3 + bd (fp32)
     int fuse_tail = 1;                  // bf16 mode, layer1: conv3 + identity + ReLU + the next block's conv1 in one kernel
     int fuse_tail3 = 1;                 // layer3.1-.4: conv3 + identity + ReLU chained with the next block's conv1 through LDS (bneck_tail3_kernel)
+    __bf16* tail3_wp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per layer3 block b: [W3(b) | W1(b+1)] in the kernel's fragment order
     int n_streams = 1;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -631,10 +632,20 @@ hipError_t launch_bneck_tail2(const void* y2, long long m, const void* w3, const
 }
 
 // layer3 shapes: conv3 (256 -> 1024) + identity + ReLU chained with the next conv1 (1024 -> 256) (kernels.h: bneck_tail3_kernel)
+// `wp`: both weight matrices in the kernel's fragment-ordered stream (1 MB; pack_tail3_weights).
 // Pixel tile: at most 112 rows; chosen so the tiles fill whole rounds of the chip (batch 256: M = 50,176 -> 98 pixels, 512 tiles).
-hipError_t launch_bneck_tail3(const void* y2, long long m, const void* w3, const float* b3, const void* res, void* out,
-                              const void* w1, const float* b1, void* y1n, hipStream_t s, int et = 0, int bp_override = 0) {
-    if (!y2 || !w3 || !b3 || !res || !out || !w1 || !b1 || !y1n || m <= 0 || m * 2048 >= (1ll << 31)) return hipErrorInvalidValue;
+constexpr size_t kTail3PackedBytes = 1u << 20;
+#if defined(R50_STAMP)
+unsigned long long* g_dbg = nullptr;         // diagnostic build: set through r50_debug_buffer()
+#endif
+hipError_t pack_tail3_weights(const void* w3, const void* w1, void* wp, hipStream_t s) {
+    if (!w3 || !w1 || !wp) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tail3_pack_kernel, dim3(65536 / 256), dim3(256), 0, s, (const __bf16*)w3, (const __bf16*)w1, (__bf16*)wp);
+    return hipGetLastError();
+}
+hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const float* b3, const void* res, void* out,
+                              const float* b1, void* y1n, hipStream_t s, int et = 0, int bp_override = 0) {
+    if (!y2 || !wp || !b3 || !res || !out || !b1 || !y1n || m <= 0 || m * 2048 >= (1ll << 31)) return hipErrorInvalidValue;
     if (g_num_cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -642,8 +653,11 @@ hipError_t launch_bneck_tail3(const void* y2, long long m, const void* w3, const
         g_num_cus = prop.multiProcessorCount;
     }
     Tail3Args a;
-    a.y2 = (const __bf16*)y2; a.w3 = (const __bf16*)w3; a.b3 = b3; a.res = (const __bf16*)res; a.out = (__bf16*)out;
-    a.w1 = (const __bf16*)w1; a.b1 = b1; a.y1n = (__bf16*)y1n; a.M = (int)m;
+    a.y2 = (const __bf16*)y2; a.wp = (const __bf16*)wp; a.b3 = b3; a.res = (const __bf16*)res; a.out = (__bf16*)out;
+    a.b1 = b1; a.y1n = (__bf16*)y1n; a.M = (int)m;
+#if defined(R50_STAMP)
+    a.dbg = g_dbg;
+#endif
     const long long rounds = ((m + 111) / 112 + g_num_cus - 1) / g_num_cus;
     long long bp = (m + rounds * g_num_cus - 1) / (rounds * g_num_cus);
     if (bp < 49) bp = 49;
@@ -652,7 +666,7 @@ hipError_t launch_bneck_tail3(const void* y2, long long m, const void* w3, const
     a.bp = (int)bp;
     a.n_tiles = (int)((m + bp - 1) / bp);
     const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
-    const size_t lds = 4 * 16384 + 4 * 112 * 128 + 2 * 112 * 128 + 256 * 4 + 1024 * 4;      // ring + resident t2 + out_c + b1 + b3
+    const size_t lds = 10 * 112 * 128 + 256 * 4 + 1024 * 4;      // t2 (4 slots) + residual (2 x 2) + out_c (2) + b1 + b3
     auto kern = et == 1 ? bneck_tail3_kernel<1> : bneck_tail3_kernel<0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1016,7 +1030,7 @@ after_pool:
             const bool fuse_ok = !split && !nx_is_fp8 && (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16 || h->precision == R50_PREC_FP8) && h->fuse_tail && h->tile_override == 0 && nx && c3.ks == 1 && c3.stride == 1 &&
                                  nx->ks == 1 && nx->stride == 1;
             const bool fuse2 = fuse_ok && c3.cin == 128 && c3.cout == 512 && nx->cin == 512 && nx->cout == 128;   // layer2 shapes
-            const bool fuse3 = fuse_ok && h->fuse_tail3 && b > 0 && c3.cin == 256 && c3.cout == 1024 && nx->cin == 1024 && nx->cout == 256;   // layer3 shapes (plain identity)
+            const bool fuse3 = fuse_ok && h->fuse_tail3 && b > 0 && b < 8 && h->tail3_wp[b] && c3.cin == 256 && c3.cout == 1024 && nx->cin == 1024 && nx->cout == 256;   // layer3 shapes (plain identity)
             const ConvLayer* cdp = (b == 0) ? &h->convs[li + 3] : nullptr;
             // layer2.0 / 3.0 / 4.0: conv3 + downsample + add + ReLU as ONE 1x1 conv over K = [t2 | block input at the block's stride]
             // against [W3 | Wd]: the downsample tensor is never written or read back, and there is one launch instead of two.
@@ -1072,7 +1086,7 @@ after_pool:
                                   (double)c3.cout * c3.cin * (fuse_ds ? 2 : 1) + (double)nx->cin * nx->cout),
                            (int)(&c3 - &h->convs[0]));
                 if (fuse3)
-                    e = launch_bneck_tail3(buf[fr[1]], m, c3.w, c3.bias, idn, buf[fr[3]], nx->w, nx->bias, buf[fr[0]], s, et);
+                    e = launch_bneck_tail3(buf[fr[1]], m, h->tail3_wp[b], c3.bias, idn, buf[fr[3]], nx->bias, buf[fr[0]], s, et);
                 else if (fuse2)
                     e = launch_bneck_tail2(buf[fr[1]], m, c3.w, c3.bias, idn, buf[fr[3]], nx->w, nx->bias, buf[fr[0]], s, et);
                 else
@@ -1110,6 +1124,7 @@ void free_all(r50_handle* h) {
         if (L.bias_scaled) (void)hipFree(L.bias_scaled);
         L.w = nullptr; L.bias = nullptr; L.bias_scaled = nullptr;
     }
+    for (auto& p : h->tail3_wp) { if (p) (void)hipFree(p); p = nullptr; }
     for (int i = 0; i < 4; ++i) {
         if (h->cat_w[i]) (void)hipFree(h->cat_w[i]);
         if (h->cat_bias[i]) (void)hipFree(h->cat_bias[i]);
@@ -1325,6 +1340,26 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
             li += 4 + 3 * (kStages[si][1] - 1);
         }
     }
+    // layer3.1-.4: conv3 of block b and conv1 of block b+1 in the chained tail kernel's fragment-ordered stream (16-bit precisions)
+    if (want_cat) {
+        size_t li = 1;
+        for (int si = 0; si < 4; ++si) {
+            const int blocks = kStages[si][1];
+            for (int b = 0; b < blocks; ++b) {
+                const size_t i3 = li + 2, inx = li + ((b == 0) ? 4 : 3);
+                if (si == 2 && b > 0 && b < 8 && inx < h->convs.size()) {
+                    const ConvLayer& c3 = h->convs[i3];
+                    const ConvLayer& nx = h->convs[inx];
+                    if (c3.ks == 1 && c3.cin == 256 && c3.cout == 1024 && nx.ks == 1 && nx.stride == 1 && nx.cin == 1024 && nx.cout == 256) {
+                        if (!h->tail3_wp[b]) HIP_TRY(h, hipMalloc((void**)&h->tail3_wp[b], kTail3PackedBytes));
+                        HIP_TRY(h, pack_tail3_weights(c3.w, nx.w, h->tail3_wp[b], nullptr));
+                    }
+                }
+                li += (b == 0) ? 4 : 3;
+            }
+        }
+        HIP_TRY(h, hipDeviceSynchronize());
+    }
     h->loaded = true;
     h->fp8_scales.clear();              // new weights: bias_scaled must be rebuilt
     return R50_OK;
@@ -1520,7 +1555,6 @@ int r50_get_packed(r50_handle* h, const char* conv_key, int what, void* dst_host
 
 // ---- op-level entry points -------------------------------------------------------------------
 #if defined(R50_STAMP)      // diagnostic build only (not declared in include/r50.h): where the kernel's cycle sums go
-static unsigned long long* g_dbg = nullptr;
 extern "C" __attribute__((visibility("default"))) void r50_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
 #endif
 
@@ -1585,7 +1619,10 @@ int r50_op_bneck_tail(const void* y2, int64_t m, int cmid, const void* w3, const
     else if (cmid == 128 && c1 == 128 && !wd && !bd) e = launch_bneck_tail2(y2, m, w3, b3, res, out, w1, b1, y1n, (hipStream_t)stream);
     else if (cmid == 256 && c1 == 256 && !wd && !bd) {
         const char* v = std::getenv("R50_TAIL3_BP");          // test / A-B knob of this debug hook: real pixels per tile (1..112); unset = automatic
-        e = launch_bneck_tail3(y2, m, w3, b3, res, out, w1, b1, y1n, (hipStream_t)stream, 0, v ? std::atoi(v) : 0);
+        static void* wp_scratch = nullptr;                     // the hook takes plain weight matrices: packed here, per call, on the caller's stream
+        if (!wp_scratch && hipMalloc(&wp_scratch, kTail3PackedBytes) != hipSuccess) return fail(nullptr, R50_ERR_HIP, "r50_op_bneck_tail: hipMalloc");
+        e = pack_tail3_weights(w3, w1, wp_scratch, (hipStream_t)stream);
+        if (e == hipSuccess) e = launch_bneck_tail3(y2, m, wp_scratch, b3, res, out, b1, y1n, (hipStream_t)stream, 0, v ? std::atoi(v) : 0);
     }
     else e = hipErrorInvalidValue;
     if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
