@@ -1207,7 +1207,11 @@ int r50_create(r50_handle** out, int device_id, int precision, int max_batch) {
         precision != R50_PREC_FP8)
         return fail(nullptr, R50_ERR_INVALID, "r50_create: unsupported precision");
     const int cmul = (precision == R50_PREC_FP32X) ? 2 : 1;
-    if (max_batch < 1 || max_batch > 1024) return fail(nullptr, R50_ERR_INVALID, "r50_create: max_batch must be in [1,1024]");
+    // The kernels address every tensor through 31-bit buffer descriptors (fill_conv_args): the largest activation, layer1's
+    // (n,56,56,256), is n x 1.6 MB in the 16-bit modes (n <= 1337) and twice that in fp32x mode ([head | tail] pairs: n <= 668).
+    const int batch_cap = (precision == R50_PREC_FP32X) ? 640 : 1024;
+    if (max_batch < 1 || max_batch > batch_cap)
+        return fail(nullptr, R50_ERR_INVALID, "r50_create: max_batch must be in [1," + std::to_string(batch_cap) + "] for this precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, R50_ERR_HIP, "r50_create: no HIP device available");

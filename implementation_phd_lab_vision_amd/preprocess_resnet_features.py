@@ -30,7 +30,7 @@ import torch
 from torch.utils.data import DataLoader, Subset
 
 from . import distributed as D
-from .prefetch import DevicePrefetcher
+from .prefetch import DevicePrefetcher, is_time_reverse_of
 from .shards import AUG_NAMES, AsyncFileWriter, ShardPacker
 
 
@@ -60,8 +60,21 @@ def build_parser() -> argparse.ArgumentParser:
                         "features of an untrained network")
     p.add_argument("--weights-seed", type=int, default=0)
     p.add_argument("--synthetic-clips", type=int, default=0, help="Use N synthetic clips instead of reading --root")
+    p.add_argument("--synthetic-decoded", action="store_true",
+                   help="--synthetic-clips: synthetic DECODED clips (uint8 frames + raw joints + camera) run through the producer, "
+                        "instead of ready-made normalised frames")
+    p.add_argument("--device-producer", action="store_true",
+                   help="Frame producer on the MI355X (producer.py): the loader hands over decoded uint8 frames, the person crop is uploaded "
+                        "once per clip, crop / resize / flip / ColorJitter / normalisation run on the device (4 variants from one upload)")
+    p.add_argument("--resize-mode", choices=["float", "fixed"], default="float",
+                   help="--device-producer: bilinear resize arithmetic.  float = torchvision's v1 functional.resize on uint8 (what the "
+                        "reference imports: fp32 + round); fixed = ATen's native uint8 kernel (the v2 API), bit-exact on the device")
     p.add_argument("--precision", choices=["bf16", "fp16", "bf16w2", "fp32x", "fp8"], default="bf16",
                    help="bf16 = the reference's CUDA autocast dtype (fast); fp32x = fp32-class accuracy (its CPU numerics), ~2.7x slower")
+    p.add_argument("--fp8-calib", choices=["first-batch", "noise"], default="first-batch",
+                   help="--precision fp8: where the 43 activation scales come from.  first-batch = the first batch of REAL clips (decoded "
+                        "once more, like the reference's warm-up batch, :235-245); noise = 8 synthetic uniform-noise frames (scales that fit "
+                        "noise, not H36M crops: anything above 448 x scale clips silently)")
     p.add_argument("--micro-batch", type=int, default=0, help="Frames per pass through the layer stack (0 = auto)")
     p.add_argument("--max-batch", type=int, default=256, help="Frames per backbone call chunk (workspace size)")
     p.add_argument("--no-trev-reuse", action="store_true",
@@ -83,6 +96,10 @@ augment_collate_fn = collate_variants       # the reference's name for it
 
 
 def _open_dataset(args):
+    if args.synthetic_clips > 0 and args.synthetic_decoded:
+        from .synthetic import SyntheticDecodedClips
+        return SyntheticDecodedClips(args.synthetic_clips, seq_len=args.seq_len, subjects=tuple(args.subjects),
+                                     augment=args.augment, stride=args.stride)
     if args.synthetic_clips > 0:
         from .synthetic import SyntheticClips
         return SyntheticClips(args.synthetic_clips, seq_len=args.seq_len, subjects=tuple(args.subjects),
@@ -129,6 +146,25 @@ def weights_digest(state_dict) -> str:
     return hsh.hexdigest()
 
 
+def _calibrate_fp8(backbone, ds, args, device, log) -> None:
+    """fp8 mode: choose the activation scales from real frames.  Every rank calibrates on the SAME clips (global batch 0, loaded by
+    each rank itself: the scales must agree across ranks or the shards would depend on the world size)."""
+    if args.fp8_calib == "noise" or len(ds) == 0:
+        log("fp8 scales : calibrated on 8 synthetic NOISE frames (--fp8-calib noise): real crops may exceed them and clip")
+    else:
+        n_clips = min(len(ds), args.batch_size)
+        videos = []
+        for i in range(n_clips):
+            item = ds[i]
+            videos.append((item[0][0] if args.augment else item[0]))            # the orig variant's (T,3,224,224) frames
+        frames = torch.cat(videos)[: args.max_batch].to(device=device, dtype=torch.float32)
+        backbone.calibrate_fp8(frames=frames)
+        log(f"fp8 scales : calibrated on the first {n_clips} clip(s) = {frames.shape[0]} real frames (margin x1.25 over their largest "
+            f"activation per tensor)")
+    sc = backbone.fp8_scales
+    log(f"fp8 scales : 43 tensors, representable range 448 x scale from {448 * min(sc):.3g} to {448 * max(sc):.3g}")
+
+
 def _resolve_device(name: str, ctx: D.RankContext) -> torch.device:
     if not name.startswith("cuda"):
         raise SystemExit(f"--device {name}: this build runs the backbone on an MI355X only (PyTorch-ROCm exposes it "
@@ -142,12 +178,6 @@ def _resolve_device(name: str, ctx: D.RankContext) -> torch.device:
     return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
 
 
-def _is_time_reverse_of(video_rev: torch.Tensor, video: torch.Tensor) -> bool:
-    """True if ``video_rev`` (B,T,3,224,224) is ``video`` flipped along T -- checked on the first and the last frame
-    of every clip (host tensors, a few MB)."""
-    return video_rev.shape == video.shape and torch.equal(video_rev[:, 0], video[:, -1]) and torch.equal(video_rev[:, -1], video[:, 0])
-
-
 def extract_features(backbone: Callable[[torch.Tensor], torch.Tensor], variants_batch, device: torch.device,
                      reuse_trev: bool = True) -> torch.Tensor:
     """The hot call site (:287-297): every variant's (B,T,3,224,224) clip batch -> (B,T,2048) fp32.
@@ -156,14 +186,15 @@ def extract_features(backbone: Callable[[torch.Tensor], torch.Tensor], variants_
     The backbone is a per-frame function, so the features of the temporal-reverse variant (``AUG_NAMES[3]``, built
     by ``_aug_temporal_reverse`` from the same clip as variant 0: src/dataset.py:199-207,424-426) are the
     features of variant 0 in reverse frame order, bit for bit: under ``--augment`` that forward pass (a quarter of
-    the work) is replaced by a flip.  Only when the frames really are the reverse (checked per batch)."""
+    the work) is replaced by a flip.  Only when the frames really are the reverse (``prefetch.is_time_reverse_of``: every frame
+    takes part in the check, per batch)."""
     per_variant = []
     for vi, (v_video, *_rest) in enumerate(variants_batch):
         if v_video is None:                            # the prefetcher found it to be the time reverse and did not upload it
             per_variant.append(per_variant[0].flip(1))
             continue
         if (reuse_trev and len(variants_batch) == len(AUG_NAMES) and vi == AUG_NAMES.index("trev")
-                and v_video.device == variants_batch[0][0].device and _is_time_reverse_of(v_video, variants_batch[0][0])):
+                and v_video.device == variants_batch[0][0].device and is_time_reverse_of(v_video, variants_batch[0][0])):
             per_variant.append(per_variant[0].flip(1))
             continue
         v_video = v_video.to(device, non_blocking=True)
@@ -174,7 +205,8 @@ def extract_features(backbone: Callable[[torch.Tensor], torch.Tensor], variants_
 
 
 def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.RankContext] = None,
-                   log: Callable[[str], None] = print, host_slots: int = 4, stats: Optional[dict] = None) -> Optional[Path]:
+                   log: Callable[[str], None] = print, host_slots: int = 4, stats: Optional[dict] = None,
+                   producer=None) -> Optional[Path]:
     """Whole job for one rank.  ``backbone(x)``: (N,3,224,224) fp32 on ``device`` -> (N,2048,1,1).
     Rank 0 packs and returns the index path; other ranks return None.
 
@@ -183,7 +215,9 @@ def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.Ran
     needs, :98,300,345).  The loop body is: forward passes of round q -> ``post`` (pack + async gather) -> ``collect`` round q-1
     (async D2H into a pinned slot, hand-over to the packing thread).  Nothing in it waits for the device, for a copy or for the
     packer, so round q+1's kernels are queued while round q's features travel and round q-1's clips are packed.
-    ``stats`` (optional dict) receives ``compute_done_s`` / ``total_s`` (seconds since the loop started)."""
+    ``stats`` (optional dict) receives ``compute_done_s`` / ``total_s`` (seconds since the loop started).
+    ``producer`` (``producer.DeviceProducer``): the loader then yields DECODED clips and crop / resize / variants / features all
+    happen on the device (``--device-producer``)."""
     ctx = ctx or D.RankContext()
     n_vars = len(AUG_NAMES) if args.augment else 1
     n_clips = len(ds)
@@ -197,9 +231,14 @@ def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.Ran
                   drop_last=False, collate_fn=collate_variants if args.augment else None)
         if args.num_workers > 0:
             kw["prefetch_factor"] = 2
-        loader = DataLoader(Subset(ds, mine) if ctx.distributed else ds, **kw)
+        src = ds
+        if producer is not None:
+            from .producer import DecodedClips, collate_decoded
+            src = DecodedClips(ds, augment=args.augment)
+            kw["collate_fn"] = collate_decoded
+        loader = DataLoader(Subset(src, mine) if ctx.distributed else src, **kw)
     it = iter(loader) if loader is not None else None
-    if it is not None:       # copy batch k+1 to the device on a side stream while batch k computes (no-op on a CPU device)
+    if it is not None and producer is None:       # copy batch k+1 to the device on a side stream while batch k computes (no-op on a CPU device)
         it = DevicePrefetcher(it, device, augment=args.augment, skip_trev=not getattr(args, "no_trev_reuse", False),
                               trev_index=AUG_NAMES.index("trev"))
 
@@ -255,14 +294,19 @@ def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.Ran
         feats = variants_batch = box_batch = None
         if q < my_batches:
             batch = next(it)
-            if args.augment:
-                variants_batch, box_batch = batch, None
+            if producer is not None:                       # decoded clips in: crop / resize / variants / features on the device
+                feats, variants_batch, box_batch = producer.compute(batch)
+                t = feats.shape[2]
             else:
-                video, j3d, j2d, k, box = batch
-                variants_batch, box_batch = [(video, j3d, j2d, k)], box
-            if variants_batch[0][0].shape[1] != args.seq_len:
-                raise RuntimeError(f"clips have {variants_batch[0][0].shape[1]} frames, --seq-len says {args.seq_len}")
-            feats = extract_features(backbone, variants_batch, device, reuse_trev=not getattr(args, "no_trev_reuse", False))
+                if args.augment:
+                    variants_batch, box_batch = batch, None
+                else:
+                    video, j3d, j2d, k, box = batch
+                    variants_batch, box_batch = [(video, j3d, j2d, k)], box
+                t = variants_batch[0][0].shape[1]
+                feats = extract_features(backbone, variants_batch, device, reuse_trev=not getattr(args, "no_trev_reuse", False))
+            if t != args.seq_len:
+                raise RuntimeError(f"clips have {t} frames, --seq-len says {args.seq_len}")
         exchange.post(q, feats, variants_batch, box_batch)
         if q > 0:
             exchange.collect(q - 1)
@@ -323,6 +367,9 @@ def main(argv: Optional[List[str]] = None) -> None:
         (Path(args.out) / "backbone_weights.json").write_text(json.dumps(
             {"source": source, "sha256": digest, "precision": args.precision, "synthetic": bool(args.synthetic_weights)}) + "\n")
 
+    if args.precision == "fp8":
+        _calibrate_fp8(backbone, ds, args, device, log)
+
     log("Warming up the HIP kernels...")                               # reference warm-up: :235-245
     warm = torch.zeros((min(args.max_batch, args.batch_size * args.seq_len), 3, 224, 224), device=device)
     backbone(warm)
@@ -330,8 +377,15 @@ def main(argv: Optional[List[str]] = None) -> None:
     del warm
     log("✓ Warmup complete\n")
 
+    producer = None
+    if args.device_producer:
+        from . import frames
+        from .producer import DeviceProducer
+        producer = DeviceProducer(backbone, device, augment=args.augment,
+                                  resize_mode=frames.RESIZE_FIXED if args.resize_mode == "fixed" else frames.RESIZE_FLOAT)
+        log(f"Producer   : on the device ({args.resize_mode} resize): one uint8 upload per clip for {n_vars} variant(s)")
     try:
-        run_extraction(ds, args, backbone, device, ctx, log)
+        run_extraction(ds, args, backbone, device, ctx, log, producer=producer)
     finally:
         backbone.close()
         D.shutdown(ctx)

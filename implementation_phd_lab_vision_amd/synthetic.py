@@ -81,3 +81,63 @@ class SyntheticClips(Dataset):
         variants.append((self._norm(torch.flip(video, dims=[3])), j3d_f, j2d_f, k_f))
         variants.append((self._norm(torch.flip(video, dims=[0])), torch.flip(j3d, dims=[0]), torch.flip(j2d, dims=[0]), k))
         return variants
+
+
+class SyntheticDecodedClips(Dataset):
+    """Synthetic stand-in one step further upstream: what the reference's dataset holds right AFTER the video decode
+    (src/dataset.py:370-393) -- uint8 (T,H,W,3) frames, raw joints and camera -- plus the reference's own host-side producer
+    (``__getitem__``: box -> crop -> resize -> /255 -> variants -> Normalize, :395-437) restated with torch ops, so that the
+    CLI's ``--device-producer`` path can be compared with the host-producer path on the same decoded clips.
+
+    The host resize is ATen's native uint8 bilinear kernel (``F.interpolate`` on a uint8 tensor = what torchvision's v2 ``resize``
+    dispatches to; ``frames.RESIZE_FIXED`` on the device).  ColorJitter lives in torchvision, which is absent here: the host path
+    takes it as ``cjitter_fn(video01 (T,3,H,W), params) -> video01`` (the tests plug the oracle's restatement in); both paths use
+    the SAME per-clip draw (``decoded_item(i)["cj_params"]``, seeded by the clip index)."""
+
+    def __init__(self, n_clips: int, seq_len: int = 40, subjects=(1, 5, 6, 7, 8, 9, 11), augment: bool = False, seed: int = 0,
+                 stride: int = 5, height: int = 260, width: int = 300, cjitter_fn=None):
+        self.seq_len, self.augment, self.seed, self.h, self.w, self.cjitter_fn = seq_len, augment, seed, height, width, cjitter_fn
+        self.crop_scale = 1.6
+        self.index = SyntheticClips(n_clips, seq_len=seq_len, subjects=subjects, seed=seed, stride=stride).index
+
+    def __len__(self) -> int:
+        return len(self.index)
+
+    def decoded_item(self, i: int) -> dict:
+        from .frames import sample_color_jitter_params
+        g = torch.Generator().manual_seed(self.seed * 1_000_003 + 7919 * i + 1)
+        t = self.seq_len
+        frames = torch.randint(0, 256, (t, self.h, self.w, 3), generator=g, dtype=torch.uint8)
+        # a "person": joints scattered around a centre that drifts over the clip; some clips hug the image border (box clipping)
+        cx = float(torch.rand(1, generator=g)) * self.w
+        cy = float(torch.rand(1, generator=g)) * self.h
+        spread = 20.0 + 60.0 * float(torch.rand(1, generator=g))
+        joints2d = torch.stack([cx + spread * torch.randn((t, 17), generator=g) * 0.3, cy + spread * torch.randn((t, 17), generator=g) * 0.5], dim=-1)
+        joints3d = torch.randn((t, 17, 3), generator=g) * 500.0
+        cam = {"f": (1145.0 + torch.rand(2, generator=g)).numpy(), "c": (torch.tensor([self.w / 2.0, self.h / 2.0]) + torch.rand(2, generator=g)).numpy()}
+        return {"frames": frames, "joints3d": joints3d, "joints2d": joints2d, "cam": cam, "crop_scale": self.crop_scale,
+                "cj_params": sample_color_jitter_params(generator=g)}
+
+    def __getitem__(self, i: int):
+        import torch.nn.functional as TF
+        from . import frames as F
+        it = self.decoded_item(i)
+        frames_u8, j3d, j2d_raw = it["frames"], it["joints3d"], it["joints2d"]
+        box = F.square_crop_from_2d(j2d_raw, self.h, self.w, scale=self.crop_scale)
+        top, left, hh, ww = box.tolist()
+        crop = frames_u8.permute(0, 3, 1, 2)[:, :, top:top + hh, left:left + ww]
+        video = TF.interpolate(crop, size=(224, 224), mode="bilinear", align_corners=False, antialias=False).to(torch.float32) / 255.0
+        j2d = F.adjust_joints2d_after_crop_and_resize(j2d_raw, box, 224)
+        k = F.adjust_camera_after_crop_and_resize(it["cam"], box, 224)
+        norm = SyntheticClips._norm
+        if not self.augment:
+            return norm(video), j3d, j2d, k, box
+        if self.cjitter_fn is None:
+            raise RuntimeError("SyntheticDecodedClips(augment=True): the host-side ColorJitter needs `cjitter_fn` (torchvision is absent)")
+        variants = [(norm(video), j3d, j2d, k)]
+        variants.append((norm(self.cjitter_fn(video, it["cj_params"])), j3d, j2d, k))
+        fj3d, fj2d, fk = F.aug_hflip_annotations(j3d, j2d, k, width=224)
+        variants.append((norm(torch.flip(video, dims=[-1])), fj3d, fj2d, fk))
+        tj3d, tj2d = F.aug_temporal_reverse_annotations(j3d, j2d)
+        variants.append((norm(torch.flip(video, dims=[0])), tj3d, tj2d, k))
+        return variants

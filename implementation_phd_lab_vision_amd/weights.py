@@ -49,12 +49,19 @@ def conv_specs() -> List[Tuple[str, str, int, int, int, int, int]]:
     return specs
 
 
-def synthetic_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
+def synthetic_state_dict(seed: int = 0, family: str = "uniform") -> Dict[str, torch.Tensor]:
     """Closed-form seeded weights (no calibration pass, so every box regenerates identical bits).
 
-    conv: Kaiming-normal, fan-out.  BN: gamma~U(0.5,1.5) (last BN of each residual branch x0.25 to
-    bound residual growth), beta~U(-0.2,0.2), running_mean~U(-0.1,0.1), running_var~U(0.5,1.5).
-    """
+    ``family="uniform"`` (the default, the benchmark's weights): conv Kaiming-normal, fan-out; BN gamma~U(0.5,1.5) (last BN of
+    each residual branch x0.25 to bound residual growth), beta~U(-0.2,0.2), running_mean~U(-0.1,0.1), running_var~U(0.5,1.5).
+
+    ``family="trained"``: the statistics a TRAINED checkpoint shows and the uniform family never does -- gamma of either sign,
+    a tenth of the channels with |gamma| ~ 1e-3 (pruned channels), running_var log-uniform over [1e-3, 10], running_mean~U(-0.5,0.5),
+    beta~U(-0.5,0.5).  Each conv output channel is scaled by sqrt(running_var) (a trained net's pre-BN activations HAVE the
+    variance its BN recorded), so activations stay O(1) while the folded per-channel scales gamma / sqrt(var + eps) span
+    four orders of magnitude -- the range the 16-bit and fp8 paths must survive."""
+    if family not in ("uniform", "trained"):
+        raise ValueError("family must be 'uniform' or 'trained'")
     g = torch.Generator(device="cpu").manual_seed(int(seed))
     sd: Dict[str, torch.Tensor] = {}
 
@@ -63,14 +70,23 @@ def synthetic_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
 
     for conv_key, bn_key, cin, cout, k, _s, _p in conv_specs():
         std = math.sqrt(2.0 / (cout * k * k))
-        sd[conv_key + ".weight"] = torch.randn(cout, cin, k, k, generator=g, dtype=torch.float32) * std
-        gamma = uni(cout, 0.5, 1.5)
+        w = torch.randn(cout, cin, k, k, generator=g, dtype=torch.float32) * std
+        if family == "uniform":
+            gamma = uni(cout, 0.5, 1.5)
+            beta, mean, var = uni(cout, -0.2, 0.2), uni(cout, -0.1, 0.1), uni(cout, 0.5, 1.5)
+        else:
+            gamma = uni(cout, 0.3, 1.5) * torch.where(torch.rand(cout, generator=g) < 0.35, -1.0, 1.0)
+            gamma = torch.where(torch.rand(cout, generator=g) < 0.1, gamma * 1e-3, gamma)
+            beta, mean = uni(cout, -0.5, 0.5), uni(cout, -0.5, 0.5)
+            var = torch.pow(10.0, uni(cout, -3.0, 1.0))
+            w = w * var.sqrt().view(-1, 1, 1, 1)
         if bn_key.endswith("bn3"):
             gamma = gamma * 0.25
+        sd[conv_key + ".weight"] = w
         sd[bn_key + ".weight"] = gamma
-        sd[bn_key + ".bias"] = uni(cout, -0.2, 0.2)
-        sd[bn_key + ".running_mean"] = uni(cout, -0.1, 0.1)
-        sd[bn_key + ".running_var"] = uni(cout, 0.5, 1.5)
+        sd[bn_key + ".bias"] = beta
+        sd[bn_key + ".running_mean"] = mean
+        sd[bn_key + ".running_var"] = var
         sd[bn_key + ".num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
     return sd
 

@@ -75,3 +75,76 @@ def test_cli_with_a_checkpoint_file(tmp_path, lib_built):
         assert torch.equal(sa["feats"], sb["feats"])
     prov = json.loads((a / "backbone_weights.json").read_text())
     assert prov["sha256"] == weights_digest(sd) and prov["synthetic"] is False and str(path) in prov["source"]
+
+
+def test_cli_fp8_calibrates_on_the_first_real_batch(tmp_path, lib_built, capsys):
+    """--precision fp8: the activation scales come from the first batch of the run's own clips (not from noise frames), the same on
+    every rank; the run completes, its features are finite and close to the bf16 run's."""
+    from implementation_phd_lab_vision_amd.preprocess_resnet_features import main
+    common = ["--root", "unused", "--synthetic-clips", "3", "--seq-len", "2", "--batch-size", "2", "--num-workers", "0",
+              "--shard-size", "4", "--shuffle-pool", "4", "--device", "cuda", "--max-batch", "8", "--synthetic-weights"]
+    a, b = tmp_path / "fp8", tmp_path / "bf16"
+    main(common + ["--out", str(a), "--precision", "fp8"])
+    text = capsys.readouterr().out
+    assert "calibrated on the first 2 clip(s) = 4 real frames" in text
+    main(common + ["--out", str(b)])
+    fa = torch.load(a / "shard_00000.pt", weights_only=True)["feats"]
+    fb = torch.load(b / "shard_00000.pt", weights_only=True)["feats"]
+    assert torch.isfinite(fa).all()
+    rel = float((fa.double() - fb.double()).norm() / fb.double().norm())
+    assert rel < 0.1, rel
+
+
+def _run_host_and_device_producer(tmp_path, augment, cjitter_fn=None):
+    """The same synthetic DECODED clips through (a) the host producer (the reference's __getitem__ restated: box, crop, ATen uint8
+    resize, /255, variants, Normalize -> fp32 frames -> upload) and (b) the device producer (one uint8 upload per clip)."""
+    from implementation_phd_lab_vision_amd import frames
+    from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
+    from implementation_phd_lab_vision_amd.preprocess_resnet_features import run_extraction
+    from implementation_phd_lab_vision_amd.producer import DeviceProducer
+    from implementation_phd_lab_vision_amd.synthetic import SyntheticDecodedClips
+    from tests.helpers import cli_args
+    dev = torch.device("cuda:0")
+    bb = ResNet50Backbone(seed=0, max_batch=32).to(dev).eval()
+    ds = SyntheticDecodedClips(5, seq_len=3, augment=augment, cjitter_fn=cjitter_fn)
+    outs = {}
+    for name in ("host", "device"):
+        out = tmp_path / name
+        args = cli_args(out, seq_len=3, batch_size=2, shard_size=3, shuffle_pool=4, shuffle_seed=5, augment=augment, save_fp16=False)
+        producer = DeviceProducer(bb, dev, augment=augment, resize_mode=frames.RESIZE_FIXED) if name == "device" else None
+        run_extraction(ds, args, bb, dev, log=lambda *_: None, producer=producer)
+        outs[name] = out
+    bb.close()
+    return outs
+
+
+def test_device_producer_equals_host_producer_byte_for_byte(tmp_path, lib_built):
+    """--device-producer, no augmentation, fixed-point resize: the output directory equals the host-producer path's tensor for tensor
+    (features, adjusted joints, intrinsics, boxes, index) -- src/dataset.py:141-152,395-405 moved onto the MI355X."""
+    from tests.helpers import assert_same_feature_cache
+    outs = _run_host_and_device_producer(tmp_path, augment=False)
+    assert_same_feature_cache(outs["device"], outs["host"])
+
+
+def test_device_producer_augment_variants(tmp_path, lib_built):
+    """--device-producer --augment: four variants from ONE uint8 upload per clip.  orig / hflip / trev rows and every annotation are
+    bit-identical to the host-producer path; the cjitter rows (device kernel vs the oracle's restatement of torchvision's
+    ColorJitter, same per-clip draw) agree to the bf16 network's sensitivity to 5e-6 input differences."""
+    from oracle.colorjitter_oracle import color_jitter as cj_oracle
+    outs = _run_host_and_device_producer(tmp_path, augment=True, cjitter_fn=lambda video, p: cj_oracle(video, p))
+    ih = torch.load(outs["host"] / "index.pt", weights_only=True)
+    idv = torch.load(outs["device"] / "index.pt", weights_only=True)
+    assert ih == idv and ih["n_variants"] == 4
+    for sid in range(ih["n_shards"]):
+        sh = torch.load(outs["host"] / f"shard_{sid:05d}.pt", weights_only=True)
+        sd_ = torch.load(outs["device"] / f"shard_{sid:05d}.pt", weights_only=True)
+        for key in ("joints3d", "joints2d", "K"):
+            assert torch.equal(sh[key], sd_[key]), (sid, key)
+        assert [m["aug"] for m in sh["meta"]] == [m["aug"] for m in sd_["meta"]]
+        for row, meta in enumerate(sh["meta"]):
+            a, b = sd_["feats"][row], sh["feats"][row]
+            if meta["aug"] == "cjitter":
+                rel = float((a.double() - b.double()).norm() / b.double().norm())
+                assert rel < 2e-2, (sid, row, rel)
+            else:
+                assert torch.equal(a, b), (sid, row, meta["aug"])
