@@ -316,7 +316,8 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
     // ---------------- compute side ----------------------------------------------------------------
     f32x4 acc[MR][NR];
     constexpr bool BIG = (MR * NR > 16);          // 128+ accumulator registers: keep the other register users small
-    constexpr bool PREFETCH_RES = !SPLIT && !BIG;
+    constexpr bool LEAN = (NT >= 1024);           // 16 waves = 4 per SIMD: 128 registers per lane, one K half's fragments at a time
+    constexpr bool PREFETCH_RES = !SPLIT && !BIG && !LEAN;
     u32x4 res_reg[PREFETCH_RES ? MR / 2 : 1][PREFETCH_RES ? NR : 1];
     const bool has_res = (a.res != nullptr);
     const int fphys0 = (fq ^ (fr & 7)) << 4;       // kk = 0; kk = 1 is ^ 64
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
     };
     auto compute = [&]() {
         const char* sbase = smem + c_buf * STAGE_BYTES;
-        if constexpr (BIG && (MR * NR + 2 * (MR + NR)) * 4 > 208) {
+        if constexpr (LEAN || (BIG && (MR * NR + 2 * (MR + NR)) * 4 > 208)) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int ph = fphys0 ^ (kk << 6);
@@ -976,6 +977,295 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv 3x3 / stride 1 / pad 1 with Cin = Cout (layer2 / layer3 / layer4 conv2 of the non-first blocks), INPUT-RESIDENT:
+// a tile's input pixels -- with their halo -- are staged into LDS ONCE per 64-channel chunk and all nine taps read them there, so
+// only the weights stream (the generic implicit GEMM re-stages the pixel rows for every tap: 9x the activation traffic from L2 into
+// LDS, which at a CU's ~40 B/clk of L2 feed makes its 128x224 tile feed-bound: 44 KB per 896 MFMA cycles).
+// Tile = 196 output pixels (13 MFMA column blocks) x BC output channels:
+//     14x14 images: one image            (NI = 1, TR = 14)      BC = 256 = all couts:  256 tiles at batch 256 = one full round
+//      7x7  images: four images          (NI = 4, TR = 7)       BC = 128:              64 x 4 = 256 tiles
+//     28x28 images: a band of 7 rows     (NI = 1, TR = 7)       BC = 128 = all couts:  1024 tiles = four rounds
+// LDS: two input buffers [NI panels of (TR+2) x (IW+2) positions][128 B] (zero border by out-of-range DMA; the next chunk's rows are
+// fetched while the current chunk's nine taps run) + a ring of three weight stages [BC rows][128 B].  Rows of 128 B, 16-B chunk c of
+// row r at chunk c ^ (r & 7).  One K-step = one tap of one chunk; the K order is (chunk, tap, channel) -- not the generic kernel's
+// (tap, chunk, channel) -- so sums differ from its in the last fp32 bits; these shapes therefore ALWAYS take this kernel, at every
+// batch size (a frame's features must not depend on the batch it travels in).
+// 8 consumer waves (cout group w & 3, pixel half w >> 2: blocks 0..6 / 7..12; waves w and w + 4 share a SIMD) + 4 loader waves.
+// ------------------------------------------------------------------------------------------------
+template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS>
+__global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PW = IW + 2, PP = (TR + 2) * PW, PPT = NI * PP;     // padded positions per panel / per tile
+    constexpr int XPASS = (PPT + 31) / 32, XBUF = XPASS * 32 * 128;
+    constexpr int NPX = NI * TR * IW, NBLK = (NPX + 15) / 16;         // 196 pixels, 13 blocks
+    static_assert(NBLK == 13, "tiles are 196 pixels");
+    constexpr int NB = IH / TR;                                       // row bands per image
+    constexpr int MR = BC / 64;                                       // 16-row cout blocks per consumer wave (4 cout groups)
+    // TPS taps per K-step: 1 (ring of 3 stages, 2 in flight) or 3 = a whole kernel row (ring of 2 long stages, 1 in flight): a step has a
+    // fixed cost of ~500 cycles (barrier skew, first fragments' LDS latency), so longer steps spend less of their time on it
+    static_assert(TPS == 1 || TPS == 3, "one tap or one kernel row per step");
+    constexpr int SPC = 9 / TPS;                                      // steps per chunk
+    constexpr int WPASS = TPS * BC / 32, WSTAGE = TPS * BC * 128, NSTAGE = (TPS == 1) ? 3 : 2, D = NSTAGE - 1;
+    constexpr int WRING = 2 * XBUF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#if defined(R50_STAMP)
+    const unsigned long long t_entry = __builtin_readcyclecounter();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grid = gridDim.x;
+    const int first = blockIdx.x;
+    const int nct = a.Cout / BC;
+    const int n_tiles = a.n_blocks;                                   // pixel tiles x cout tiles (cout tile fastest)
+    const int my_tiles = (n_tiles - first + grid - 1) / grid;
+    const int cch = a.cin_chunks;
+    const int spt = SPC * cch;                                        // steps per tile
+    const int total = my_tiles * spt;
+
+    if (wave >= 8) {
+        // =============================== loader waves ===============================================
+        const int lw = wave - 8;
+        const int lt = tid - 512;
+        const int srow = lt >> 3, slot = lt & 7;
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w), 0, a.w_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, (unsigned)a.M * (unsigned)(a.Cin * 2), 0x00020000);
+        unsigned w_voff[WPASS], x_voff[XPASS];
+        auto decode_w = [&](int tile) {
+            const int c0 = (tile % nct) * BC;
+#pragma unroll
+            for (int i = 0; i < WPASS; ++i) {
+                const int row = i * 32 + srow;                           // stage row: tap row / BC of the step, channel row % BC
+                const int tt = row / BC, rho = row - tt * BC;
+                const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+                w_voff[i] = (unsigned)((c0 + cl) * a.Ktot + tt * a.Cin + (slot ^ (rho & 7)) * 8) * 2u;
+            }
+        };
+        auto decode_x = [&](int tile) {           // source offsets of the padded positions of `tile` (out of range = zero border)
+            const int pt = tile / nct;
+            const int band = pt % NB, n0 = (pt / NB) * NI;
+#pragma unroll
+            for (int i = 0; i < XPASS; ++i) {
+                const int q = i * 32 + srow;
+                const int panel = q / PP, rem = q - panel * PP;
+                const int rr = rem / PW, cc = rem - rr * PW;
+                const int n = n0 + panel, y = band * TR + rr - 1, x = cc - 1;
+                const bool ok = q < PPT && tile < n_tiles && n < a.N && (unsigned)y < (unsigned)IH && (unsigned)x < (unsigned)IW;
+                x_voff[i] = ok ? (unsigned)(((n * IH + y) * IW + x) * a.Cin + (slot ^ (q & 7)) * 8) * 2u : kOobOffset;
+            }
+        };
+        // stream position of the NEXT step to issue, and of the input chunk that is fetched beside it (one chunk ahead)
+        int i_tile = first, i_c = 0, i_s = 0, i_buf = 0;
+        int x_tile = first, x_c = 0, x_par = 0;                       // chunk being fetched: tile, chunk, buffer
+        auto x_issue = [&](int p0, int p1) {                         // passes [p0, p1) of chunk (x_tile, x_c) into buffer x_par
+            const int xofs = __builtin_amdgcn_readfirstlane(x_c * 128);
+#pragma unroll
+            for (int i = 0; i < XPASS; ++i)
+                if (i >= p0 && i < p1)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + x_par * XBUF + i * 4096 + lw * 1024), 16, x_voff[i], xofs, 0, 0);
+        };
+        // X passes issued beside tap s of a chunk: taps 2..8 carry two passes each (the buffer being refilled was read until tap 8 of the
+        // PREVIOUS chunk, and this loader runs at most D = 2 steps ahead of the consumers)
+        // (TPS = 3: the three steps of a chunk; the loader is one step ahead, so step 0 of a chunk may still overlap the previous chunk's
+        // last step: passes go beside steps 1 and 2)
+        constexpr int XS0 = (TPS == 1) ? 2 : 1, XPS = (TPS == 1) ? 2 : (XPASS + 1) / 2;     // first step that carries passes, passes per step
+        auto xp_lo = [&](int s) { return s < XS0 ? XPASS : (XPS * (s - XS0) < XPASS ? XPS * (s - XS0) : XPASS); };
+        auto xp_hi = [&](int s) { return s < XS0 ? XPASS : (XPS * (s - XS0 + 1) < XPASS ? XPS * (s - XS0 + 1) : XPASS); };
+        static_assert(XPS * (SPC - XS0) >= XPASS, "the chunk's steps carry all input passes");
+        auto ops_of = [&](int g) -> int {         // LDS-DMA instructions of stream step g (per loader wave); 0 past the end
+            if (g >= total) return 0;
+            const int s = g % SPC;
+            const bool has_next_chunk = (g / SPC) + 1 < my_tiles * cch;
+            return WPASS + (has_next_chunk ? xp_hi(s) - xp_lo(s) : 0);
+        };
+        decode_w(i_tile);
+        decode_x(x_tile);
+        x_issue(0, XPASS);                        // the first chunk's input, whole
+        // advance the fetched chunk to (first tile, chunk 1) or the next tile's chunk 0
+        auto x_advance = [&]() {
+            x_par ^= 1;
+            if (++x_c == cch) { x_c = 0; x_tile += grid; decode_x(x_tile); }
+        };
+        x_advance();
+        auto stage_issue = [&](int g) {
+            const int wofs = __builtin_amdgcn_readfirstlane((i_s * TPS * a.Cin + i_c * 64) * 2);
+            char* sbase = smem + WRING + i_buf * WSTAGE + lw * 1024;
+#pragma unroll
+            for (int i = 0; i < WPASS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LDS_AS void*)(sbase + i * 4096), 16, w_voff[i], wofs, 0, 0);
+            const bool has_next_chunk = (g / SPC) + 1 < my_tiles * cch;
+            if (has_next_chunk && i_s >= XS0) x_issue(xp_lo(i_s), xp_hi(i_s));
+            i_buf = (i_buf == NSTAGE - 1) ? 0 : i_buf + 1;
+            if (++i_s == SPC) {
+                i_s = 0;
+                if (has_next_chunk) x_advance();
+                if (++i_c == cch) {
+                    i_c = 0;
+                    i_tile += grid;
+                    if (i_tile < n_tiles) decode_w(i_tile);
+                }
+            }
+        };
+        static_assert(WPASS + XPS <= 63, "vmcnt is 6 bits");
+        auto wait_younger = [&](int n) {          // all but the n youngest vector-memory operations of this wave are complete
+            if (n <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+            bool done = false;
+#pragma unroll
+            for (int e = 0; e <= XPS; ++e)
+                if (!done && n == WPASS + e) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPASS + e) : "memory"); done = true; }
+            if (!done) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        };
+#pragma unroll
+        for (int g0 = 0; g0 < D; ++g0)
+            if (g0 < total) stage_issue(g0);
+        wait_younger(D == 2 ? ops_of(1) : 0);     // step 0 (and the first chunk's input, issued before it) landed
+        __builtin_amdgcn_s_barrier();
+        R50_STAMP_DECL
+        for (int g = 0; g < total; ++g) {
+            if (g + D < total) stage_issue(g + D);
+            R50_MARK(0)                           // DMA issue
+            wait_younger(D == 2 ? ops_of(g + 2) : 0);   // step g+1 landed (steps issued so far: .. g+D; with D = 1 it is the youngest)
+            R50_MARK(1)                           // wait landed
+            __builtin_amdgcn_s_barrier();
+            R50_MARK(2)                           // barrier
+        }
+        R50_STAMP_FLUSH(12)
+    } else {
+        // =============================== consumer waves =============================================
+        const int wave_c = wave & 3, wave_p = wave >> 2;
+        const int fr = lane & 15, fq = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+        const int w_row = (wave_c * MR * 16 + fr) * 128;                // + m*2048
+        const int w_ph0 = (fq ^ (fr & 7)) << 4;                         // kk = 0; kk = 1 is ^ 64
+        const int cout_lane = wave_c * MR * 16 + 8 * fq;
+        // this lane's pixel of each of the wave's blocks: padded position at tap (0,0) (block 13 of the second half does not exist)
+        int q0[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            int p = 16 * (7 * wave_p + j) + fr;
+            p = p < NPX ? p : NPX - 1;
+            const int panel = p / (TR * IW), rem = p - panel * (TR * IW);
+            const int r = rem / IW, c = rem - r * IW;
+            q0[j] = panel * PP + r * PW + c;
+        }
+        f32x4 acc[MR][7];
+        int c_buf = 0, x_par = 0;
+        auto run_steps = [&](auto nrw_c) {
+            constexpr int NRW = decltype(nrw_c)::value;                 // 7 blocks (first pixel half) or 6
+            constexpr int PD = 3;                                       // pixel fragments read ahead of their MFMAs
+            R50_STAMP_DECL
+#if defined(R50_STAMP)
+            const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+            st_sum[5] = clk0 - t_entry;                                 // kernel entry -> first stage landed (prologue)
+#endif
+            for (int tile = first; tile < n_tiles; tile += grid) {
+                const int c0 = (tile % nct) * BC;
+#pragma unroll
+                for (int t = 0; t < MR / 2; ++t) {
+                    const f32x4 b_lo = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t);
+                    const f32x4 b_hi = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t + 4);
+#pragma unroll
+                    for (int j = 0; j < NRW; ++j) { acc[2 * t][j] = b_lo; acc[2 * t + 1][j] = b_hi; }
+                }
+                for (int c = 0; c < cch; ++c) {
+                    const char* xb = smem + x_par * XBUF;
+                    for (int s = 0; s < SPC; ++s) {
+#pragma unroll
+                      for (int tt = 0; tt < TPS; ++tt) {
+                        const int tap = s * TPS + tt;
+                        const int kh = tap / 3, kw = tap - 3 * kh;
+                        const int toff = kh * PW + kw;
+                        const char* wb = smem + WRING + c_buf * WSTAGE + tt * (BC * 128) + w_row;
+                        // 2 x NRW slots t = NRW kk + j: one pixel fragment, MR MFMAs; the fragment of slot t + PD is read when slot t issues
+                        auto xread = [&](int t) {
+                            const int row = q0[t % NRW] + toff;
+                            return *reinterpret_cast<const bf16x8*>(xb + row * 128 + ((((t >= NRW ? 4 : 0) + fq) ^ (row & 7)) << 4));
+                        };
+                        // order pinned with sched_group_barrier: hoisted by the compiler, the reads of a whole step (three taps) are live at once
+                        constexpr bool W2 = (MR <= 2);                  // both K halves' weight fragments up front (registers permitting)
+                        bf16x8 x[2 * NRW], wf[MR], wg[W2 ? MR : 1];
+#pragma unroll
+                        for (int m = 0; m < MR; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(wb + m * 2048 + w_ph0);
+                        if constexpr (W2) {
+#pragma unroll
+                            for (int m = 0; m < MR; ++m) wg[m] = *reinterpret_cast<const bf16x8*>(wb + m * 2048 + (w_ph0 ^ 64));
+                        }
+#pragma unroll
+                        for (int t = 0; t < PD; ++t) x[t] = xread(t);
+#pragma unroll
+                        for (int t = 0; t < 2 * NRW; ++t) {
+                            if constexpr (!W2) {
+                                if (t == NRW) {
+#pragma unroll
+                                    for (int m = 0; m < MR; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(wb + m * 2048 + (w_ph0 ^ 64));
+                                }
+                            }
+#pragma unroll
+                            for (int m = 0; m < MR; ++m) acc[m][t % NRW] = mfma_e<ET>((W2 && t >= NRW) ? wg[m] : wf[m], x[t], acc[m][t % NRW]);
+                            if (t + PD < 2 * NRW) x[t + PD] = xread(t + PD);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x100, (W2 ? 2 * MR : MR) + PD, 0);
+#pragma unroll
+                        for (int t = 0; t < 2 * NRW; ++t) {
+                            if (!W2 && t == NRW) __builtin_amdgcn_sched_group_barrier(0x100, MR, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);
+                            if (t + PD < 2 * NRW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                      }
+                        c_buf = (c_buf == NSTAGE - 1) ? 0 : c_buf + 1;
+#if defined(R50_STAMP)
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_nop 0" ::"v"(acc[MR - 1][NRW - 1]), "v"(acc[0][NRW - 1]) : "memory");   // the stamp waits for the last MFMAs
+#endif
+                        R50_MARK(1)                                     // fragment reads + MFMAs
+                        __builtin_amdgcn_sched_barrier(0);              // the barrier stays behind the step's last fragment read
+                        __builtin_amdgcn_s_barrier();
+                        R50_MARK(2)                                     // barrier
+                    }
+                    x_par ^= 1;
+                }
+                R50_MARK(0)                                             // (tile begin of the next tile lands here too)
+                // ---- epilogue: ReLU, 16-bit, one 16-B store per pixel and block pair
+                const int pt = tile / nct;
+                const int band = pt % NB, n0 = (pt / NB) * NI;
+#pragma unroll
+                for (int j = 0; j < NRW; ++j) {
+                    const int p = 16 * (7 * wave_p + j) + fr;
+                    const int pc = p < NPX ? p : NPX - 1;
+                    const int panel = pc / (TR * IW), rem = pc - panel * (TR * IW);
+                    const int r = rem / IW, cx = rem - r * IW;
+                    const int n = n0 + panel;
+                    const bool ok = p < NPX && n < a.N;
+                    const unsigned pix = (unsigned)((n * IH + band * TR + r) * IW + cx);
+#pragma unroll
+                    for (int t = 0; t < MR / 2; ++t) {
+                        const f32x4 lo = acc[2 * t][j], hi = acc[2 * t + 1][j];
+                        u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+                        if (a.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                        }
+                        const unsigned voff = ok ? (pix * (unsigned)a.Cout + (unsigned)(c0 + cout_lane + 32 * t)) * 2u : kOobOffset;
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff, 0, 0);
+                    }
+                }
+                R50_MARK(3)                                             // epilogue
+            }
+#if defined(R50_STAMP)
+            st_sum[6] = __builtin_readcyclecounter() - clk0;            // shader cycles and 100-MHz ticks of the whole loop: the clock the chip held
+            st_sum[7] = __builtin_amdgcn_s_memrealtime() - rt0;
+#endif
+            R50_STAMP_FLUSH(12)
+        };
+        __builtin_amdgcn_s_barrier();             // step 0 and the first input chunk landed
+        if (wave_p == 0) run_steps(std::integral_constant<int, 7>{});
+        else run_steps(std::integral_constant<int, 6>{});
+    }
+#else
+    (void)a;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Bottleneck tail (layer1): conv3 1x1 (64 -> 256) + bn3 + identity + ReLU, and the NEXT block's
 // conv1 1x1 (256 -> C1) + bn1 + ReLU, in one pass over the pixels.
 // Why: at 56x56 these two layers are HBM-bound (the block output is 2*M*256 bytes, written by conv3 and read
@@ -1543,14 +1833,16 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
         const int c_frag = (w >> 1) * SLOT + x_frag + (((4 * (w & 1) + fq) ^ (fr & 7)) << 4);
         f32x4 accA[2][NR], accB[4][NR];
         bf16x8 wA[4], wB[4];
-        auto w_load = [&](int gs, bf16x8 (&wf)[4]) {     // weight fragments of step gs (0..63 of a tile; the stream is the same for every tile)
+        // weight fragments of step gs (0..63 of a tile; the stream is the same for every tile), K half kk: wf[kk] (m = 0), wf[2 + kk] (m = 1)
+        auto w_load_half = [&](int gs, bf16x8 (&wf)[4], int kk) {
             const int sofs = __builtin_amdgcn_readfirstlane((gs & 63) * 16384);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                if constexpr (T3_ABL & 16) wf[f] = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)gs, 1u, 2u, 3u});
-                else wf[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wp, wp_voff + f * 1024, sofs, 0));
+            for (int m = 0; m < 2; ++m) {
+                if constexpr (T3_ABL & 16) wf[2 * m + kk] = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)gs, 1u, 2u, 3u});
+                else wf[2 * m + kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wp, wp_voff + (2 * m + kk) * 1024, sofs, 0));
             }
         };
+        auto w_load = [&](int gs, bf16x8 (&wf)[4]) { w_load_half(gs, wf, 0); w_load_half(gs, wf, 1); };
         // one weight step: acc[m][j] += W[32w + 16m ..][64 K] . X[64 K][16 j ..].  A single set of pixel fragments (the kernel sits at
         // the 256-register limit): the K = 32..63 fragment of pixel block j replaces the K = 0..31 one as soon as that block's MFMAs
         // are issued and is consumed 14 MFMAs later; then the fragments of step gs + 2 are requested into the registers this step
@@ -1573,16 +1865,19 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
                 acc1[j] = mfma_e<ET>(wf[2 + kk], x[t], acc1[j]);
                 }
                 if (t + PD < NS) x[t + PD] = xread(t + PD);
+                // the K half this step has just finished with is requested for step gs + 2 at once (half a step earlier than at the
+                // step's end: the loads come from L2 while every other CU streams too, and one step of cover is not enough)
+                if (t == NR - 1) w_load_half(gs + 2, wf, 0);
             }
-            w_load(gs + 2, wf);
+            w_load_half(gs + 2, wf, 1);
             __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
 #pragma unroll
-            for (int t = 0; t < NS - PD; ++t) {
+            for (int t = 0; t < NS; ++t) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (t + PD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (t == NR - 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * PD, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
         };
         w_load(0, wA);
         w_load(1, wB);

@@ -395,6 +395,47 @@ hipError_t launch_conv3x3_c64(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// conv2 of the non-first blocks of layer2 / layer3 / layer4 (3x3 s1 p1, Cin = Cout): input-resident kernel (kernels.h: conv3x3_xres_kernel);
+// tile id 64+17.  Chosen for these shapes at EVERY batch size: its K order differs from the generic kernel's.
+constexpr int kTileXres = kWsBit | 17;
+bool is_xres_shape(const ConvArgs& a) {
+    if (!(a.ks == 3 && a.stride == 1 && a.pad == 1 && a.Cin == a.Cout && a.H == a.W && a.res == nullptr && a.x2 == nullptr &&
+          a.x_cstride == a.Cin && a.y_cstride == a.Cout && a.Ktot == 9 * a.Cin && a.et != 2)) return false;
+    return (a.H == 14 && a.Cin == 256) || (a.H == 7 && a.Cin == 512) || (a.H == 28 && a.Cin == 128);
+}
+template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS>
+hipError_t launch_conv3x3_xres_t(ConvArgs a, hipStream_t s) {
+    constexpr int PPT = NI * (TR + 2) * (IW + 2), XBUF = (PPT + 31) / 32 * 32 * 128;
+    constexpr size_t lds = 2 * (size_t)XBUF + (TPS == 1 ? 3 : 2) * (size_t)TPS * BC * 128;
+    static_assert(lds <= 163840, "LDS budget");
+    auto kern = conv3x3_xres_kernel<ET, BC, NI, TR, IW, IH, TPS>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        g_num_cus = prop.multiProcessorCount;
+    }
+    a.n_ctiles = a.Cout / BC;
+    a.n_blocks = ((a.N + NI - 1) / NI) * (IH / TR) * a.n_ctiles;
+    const int grid = a.n_blocks < g_num_cus ? a.n_blocks : g_num_cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, s, a);
+    return hipGetLastError();
+}
+template <int ET>
+hipError_t launch_conv3x3_xres(const ConvArgs& a, hipStream_t s) {
+    if (!is_xres_shape(a)) return hipErrorInvalidValue;
+    // 14x14: 128 couts x one image x one tap per step (512 tiles = two full rounds at batch 256).  Measured in the network at batch 256
+    // (bench.py, same box, two rounds each): generic tuned tile 82.2-82.5 k frames/s; this 83.1-83.2 k; 256 couts per tile (112
+    // accumulator registers, spills outside the loop) 83.1-83.2 k; a whole kernel row per step (TPS = 3, ring of two 48-KB stages) 82.0 k.
+    static const int var = [] { const char* v = std::getenv("R50_XRES_VARIANT"); return v ? std::atoi(v) : 0; }();    // A/B knob
+    if (a.H == 14) return var == 1 ? launch_conv3x3_xres_t<ET, 256, 1, 14, 14, 14, 1>(a, s)
+                        : var == 3 ? launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 3>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1>(a, s);
+    if (a.H == 7) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1>(a, s);
+    return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1>(a, s);
+}
+
 // tiles a launch of tile id `tile` would have (0 if the id does not divide this Cout)
 long long tiles_of(const ConvArgs& a, int tile) {
     int bc = 0, bp = 0;
@@ -407,7 +448,7 @@ long long tiles_of(const ConvArgs& a, int tile) {
         switch (tile & (kPersistBit - 1)) {
             case 1: case 8: bc = 128; bp = 128; break;  case 2: bc = 64; bp = 128; break;   case 3: bc = 64; bp = 256; break;
             case 5: bc = 128; bp = 64; break;           case 6: bc = 256; bp = 128; break;  case 7: bc = 128; bp = 256; break;
-            case 9: case 10: bc = 256; bp = 256; break; case 11: bc = 256; bp = 208; break; case 12: bc = 256; bp = 224; break;
+            case 9: case 10: bc = 256; bp = 256; break; case 11: bc = 256; bp = 208; break; case 12: case 13: bc = 256; bp = 224; break; case 14: bc = 128; bp = 256; break;
             default: return 0;
         }
     }
@@ -415,8 +456,10 @@ long long tiles_of(const ConvArgs& a, int tile) {
     return (long long)(a.Cout / bc) * ((a.M + bp - 1) / bp);
 }
 
+int g_use_xres = [] { const char* v = std::getenv("R50_XRES"); return v ? std::atoi(v) : 1; }();      // A/B knob: 0 = generic igemm tiles for the 3x3 s1 shapes
 int auto_tile(const ConvArgs& a) {
     if (is_c64_shape(a)) return kTileC64;
+    if (g_use_xres && is_xres_shape(a)) return kTileXres;
     const long long want = 200;           // of 256 CUs: below that a launch leaves too much of the chip idle
     if (a.N >= 48 && a.H == a.W)
         for (const TunedTile& t : kTuned)
@@ -446,9 +489,10 @@ hipError_t launch_igemm_et(const ConvArgs& a, int tile, hipStream_t s, bool spli
         return launch_igemm_t<0, 128, 128, 2, 2, 2, true>(a, false, s);
     }
     if (tile == 0) tile = auto_tile(a);
-    if (a.x2 && (!(tile & kWsBit) || tile == kTileC64)) return hipErrorInvalidValue;     // two K sources: igemm_ws_kernel only
+    if (a.x2 && (!(tile & kWsBit) || tile == kTileC64 || tile == kTileXres)) return hipErrorInvalidValue;     // two K sources: igemm_ws_kernel only
     const bool pers = (tile & kPersistBit) != 0;
     if (tile == kTileC64) return launch_conv3x3_c64<ET>(a, s);
+    if (tile == kTileXres) return launch_conv3x3_xres<ET>(a, s);
     if (tile & kWsBit) {
         // <couts, pixels, consumer waves (couts x pixels), loader waves, LDS stages>
         switch (tile & (kPersistBit - 1)) {
@@ -475,6 +519,9 @@ hipError_t launch_igemm_et(const ConvArgs& a, int tile, hipStream_t s, bool spli
         case 10: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<ET, 256, 256, 2, 4, 2>(a, pers, s);
         case 11: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<ET, 256, 208, 8, 1, 2>(a, pers, s);
         case 12: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<ET, 256, 224, 4, 2, 2>(a, pers, s);
+        // 16 waves (4 per SIMD: a register-resident MFMA loop sustains 1.63 / 1.96 / 2.29 PFLOP/s at 1 / 2 / 4 waves per SIMD), wave tile 32c x 112p
+        case 13: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<ET, 256, 224, 8, 2, 2>(a, pers, s);
+        case 14: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<ET, 128, 256, 4, 4, 3>(a, pers, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -54,6 +54,11 @@ CONV_CASES = [
     (2, 14, 14, 256, 256, 3, 1, 1, True, False),
     (3, 56, 56, 64, 64, 3, 1, 1, True, False),     # layer1 conv2: resident-weights kernel (TILE_C64); 42 tiles, image borders
     (1, 56, 56, 64, 64, 3, 1, 1, False, False),
+    # input-resident 3x3 kernel (TILE_XRES): image counts that leave panels empty (7x7: four images per tile), row bands (28x28),
+    # several tiles per workgroup is covered at batch 256 by tests/test_benchmarked_config_gpu.py
+    (5, 7, 7, 512, 512, 3, 1, 1, True, False),
+    (3, 28, 28, 128, 128, 3, 1, 1, True, False),
+    (3, 14, 14, 256, 256, 3, 1, 1, False, False),
 ]
 
 
@@ -94,6 +99,8 @@ def test_conv2d_matches_oracle(lib_built, case):
     tiles = _tiles_for(cout)
     if (h, w, cin, cout, k, stride, pad, has_res) == (56, 56, 64, 64, 3, 1, 1, False):
         tiles = tiles + [ops.TILE_C64]
+    if (k, stride, pad, has_res) == (3, 1, 1, False) and (h, w, cin, cout) in ((28, 28, 128, 128), (14, 14, 256, 256), (7, 7, 512, 512)):
+        tiles = tiles + [ops.TILE_XRES]
     for tile in tiles:
         # guard band behind the result: the tile rows past M (ragged last tile) must not be stored anywhere
         numel = n * ho * wo * cout
