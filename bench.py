@@ -100,24 +100,29 @@ def cpu_baseline(sample_frames: int = 64, reps: int = 5, accuracy_of: dict = Non
     return out
 
 
-def timed_steps(step, fence, steps: int, warmup: int, preheat_s: float, frames_per_step: int):
+def timed_steps(step, fence, steps: int, warmup: int, preheat_s: float, frames_per_step: int, sync_max=None):
     """W untimed warm-up steps, an untimed pre-heat of the same step lasting >= preheat_s (clocks / power at their
-    steady state before the clock starts), then EXACTLY `steps` timed steps between two fences."""
+    steady state before the clock starts), then EXACTLY `steps` timed steps between two fences.
+    ``sync_max(x)``: MAX over the ranks of a float (multi-rank runs: every rank must run the SAME number of pre-heat steps,
+    a step contains a collective)."""
     for _ in range(warmup):
         step()
     fence()
     pre_rate = None
     if preheat_s > 0:
-        n = 0
         t0 = time.perf_counter()
-        while True:
-            for _ in range(10):
-                step()
-            n += 10
-            fence()
-            if time.perf_counter() - t0 >= preheat_s:
-                break
-        pre_rate = n * frames_per_step / (time.perf_counter() - t0)
+        for _ in range(10):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if sync_max is not None:
+            dt = sync_max(dt)
+        more = max(0, int(((preheat_s - dt) / (dt / 10)) + 0.999))
+        more = min(more, 100000)
+        for _ in range(more):
+            step()
+        fence()
+        pre_rate = (10 + more) * frames_per_step / (time.perf_counter() - t0)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -219,12 +224,18 @@ def main() -> None:
     from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
     from implementation_phd_lab_vision_amd.weights import synthetic_frames, synthetic_state_dict
 
-    dev = torch.device("cuda", local_rank)
+    # R50_BENCH_REHEARSAL=1: control-flow rehearsal of the N > 1 path on a ONE-GPU box (every rank on cuda:0, gloo collectives on device
+    # tensors) -- checks that all ranks run the same sequence of collectives; its numbers mean nothing
+    rehearsal = os.environ.get("R50_BENCH_REHEARSAL") == "1"
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if rank == 0:
         _lib.build_library()
@@ -262,6 +273,12 @@ def main() -> None:
     feats = torch.empty((args.batch, 2048), dtype=torch.float32, device=dev)
     gathered = [torch.empty_like(feats) for _ in range(world)] if (dist is not None and rank == 0) else None
 
+    def gather_feats():
+        if rehearsal:                    # gloo has no device-tensor gather: through host copies (control flow only)
+            dist.gather(feats.cpu(), [g.cpu() for g in gathered] if rank == 0 else None, dst=0)
+        else:
+            dist.gather(feats, gathered, dst=0)
+
     if args.from_host:
         x_host = x.cpu().pin_memory()
         xbuf = [x, torch.empty_like(x)]
@@ -284,12 +301,12 @@ def main() -> None:
             consumed[k & 1].record(cur)
             state["k"] = k + 1
             if dist is not None:
-                dist.gather(feats, gathered, dst=0)
+                gather_feats()
     else:
         def step():
             run(x, out=feats)
             if dist is not None:
-                dist.gather(feats, gathered, dst=0)
+                gather_feats()
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -300,7 +317,14 @@ def main() -> None:
     if args.stream_frames:          # fixed total work: rank r owns the contiguous frame range [r*per, (r+1)*per) of the stream
         per_rank = (args.stream_frames + world - 1) // world
         args.steps = max(1, (per_rank + args.batch - 1) // args.batch)
-    elapsed, preheat_rate = timed_steps(step, fence, args.steps, args.warmup, args.preheat, world * args.batch)
+    def sync_max(v: float) -> float:
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed, preheat_rate = timed_steps(step, fence, args.steps, args.warmup, args.preheat, world * args.batch, sync_max)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -338,18 +362,18 @@ def main() -> None:
         ig = prof["igemm"]
         achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         traffic = None          # HBM bytes per igemm launch from rocprofv3 PMC passes (scripts/pmc_bench.sh), committed
-        tpath = ROOT / "profiles" / "r01_pmc_hbm_traffic.json"
+        tpath = ROOT / "profiles" / "r02_pmc_hbm_traffic.json"
         if tpath.exists():
             try:
                 traffic = json.loads(tpath.read_text())["igemm"]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": "igemm_bf16_kernel + igemm_ws_kernel + conv3x3_c64_kernel (%d conv launches/step)" % round(ig["launches"] / max(1, args.steps)), "achieved": achieved,
+        roofline = {"bound": "mfma", "kernel": "igemm_bf16_kernel + igemm_ws_kernel + conv3x3_c64_kernel + conv3x3_xres_kernel (%d conv launches/step)" % round(ig["launches"] / max(1, args.steps)), "achieved": achieved,
                     "peak": (MFMA_FP8_PEAK_TFLOPS if args.precision == "fp8" else MFMA_BF16_PEAK_TFLOPS), "unit": "TFLOP/s",
                     "frac": achieved / (MFMA_FP8_PEAK_TFLOPS if args.precision == "fp8" else MFMA_BF16_PEAK_TFLOPS),
                     "traffic": traffic,
                     "traffic_note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch, batch 256, from "
-                                    "profiles/r01_pmc_hbm_traffic.json; algorithmic layer-wise bytes/launch = "
+                                    "profiles/r02_pmc_hbm_traffic.json; algorithmic layer-wise bytes/launch = "
                                     "layerwise_GBps x avg_launch_us",
                     "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
                     "flops_per_launch": ig["flops"] / max(1, ig["launches"]),
@@ -407,7 +431,7 @@ def main() -> None:
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if args.stream_frames else "weak",
             "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "fp16", "bf16w2": "bf16 (weights as bf16 head+tail pairs)",
                                             "fp32x": "bf16x3 (fp32-class)", "fp8": "fp8 e4m3 (layer2-4; stem + layer1 bf16)"}[args.precision],
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo; not a measurement)" if rehearsal else ""),
             "config": {"workload": f"ResNet-50[:-1] {args.precision} forward, batch {args.batch} x 224x224x3 fp32 NCHW frames per GPU "
                                    f"(BASELINE configs[{4 if args.precision == 'fp8' else 1}]), seeded synthetic weights, (N,2048) fp32 features"
                                    + (", RCCL gather to rank 0" if world > 1 else ""),

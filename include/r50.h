@@ -98,7 +98,8 @@ int r50_forward_layer(r50_handle* h, const float* x_nchw_f32_dev, int n, const c
  * "profile" (1 = bracket every kernel launch with HIP events, see r50_profile_*),
  * "streams" (1..4: split the batch over internal streams forked from / joined to the caller's; default 1),
  * "overlap_ds" (1 = downsample convs on a side stream; default 0), "fused_stem" (default 1),
- * "fuse_tail" (layer1: conv3 + identity + ReLU + the next block's conv1 in one kernel; default 1),
+ * "fuse_tail" (layer1 / layer2: conv3 + identity + ReLU + the next block's conv1 in one kernel; default 1),
+ * "fuse_tail3" (layer3.1-.4: the same pair chained through LDS in one launch; default 1; needs "fuse_tail"),
  * "tile" (force an igemm tile id for every conv, 0 = tuned table; also turns "fuse_tail" off). */
 int r50_set_option(r50_handle* h, const char* key, int64_t value);
 int r50_get_option(r50_handle* h, const char* key, int64_t* value);
@@ -181,7 +182,9 @@ int r50_op_maxpool(const void* x_nhwc_bf16, int n, int h, int w, int c, void* y_
  * `identity` is the block INPUT (m,64) and the identity is `downsample(x)` = bf16(wd . x + bd), computed in
  * the kernel with the same rounding as a separate launch.  All tensors bf16 NHWC with m = n*h*w pixels,
  * weights folded (cout, cin) K-contiguous, biases fp32.  cmid = 64 reproduces the two separate launches bit
- * for bit; cmid = 128 sums the second conv's K in eight slices (fp32), i.e. within rounding of them. */
+ * for bit; cmid = 128 sums the second conv's K in eight slices (fp32), i.e. within rounding of them; cmid = 256
+ * (c1 = 256, layer3: the chained kernel, weights packed into fragment order per call by this hook) is bit for
+ * bit again.  (Environment R50_TAIL3_BP = 1..112: pixels per tile of the cmid = 256 kernel, a test knob.) */
 int r50_op_bneck_tail(const void* y2_bf16, int64_t m, int cmid, const void* w3_bf16, const float* b3,
                       const void* identity_bf16, const void* wd_bf16, const float* bd, void* out_bf16, const void* w1_bf16,
                       int c1, const float* b1, void* y1n_bf16, void* stream);

@@ -66,9 +66,9 @@ def _tiles_for(cout):
     from implementation_phd_lab_vision_amd import ops
     t = [ops.TILE_AUTO, ops.TILE_64x128, ops.TILE_64x256]
     if cout % 128 == 0:
-        t += [ops.TILE_128x128, ops.TILE_128x64, ops.TILE_128x256_P3, ops.TILE_128x128_P3]
+        t += [ops.TILE_128x128, ops.TILE_128x64, ops.TILE_128x256_P3, ops.TILE_128x128_P3, ops.TILE_128x256_W16]
     if cout % 256 == 0:
-        t += [ops.TILE_256x128_P3, ops.TILE_256x256, ops.TILE_256x256_B, ops.TILE_256x208, ops.TILE_256x224]
+        t += [ops.TILE_256x128_P3, ops.TILE_256x256, ops.TILE_256x256_B, ops.TILE_256x208, ops.TILE_256x224, ops.TILE_256x224_W16]
     ws = [ops.WS | 9]
     if cout % 128 == 0:
         ws += [ops.WS | 1, ops.WS | 4, ops.WS | 8]
