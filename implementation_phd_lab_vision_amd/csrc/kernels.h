@@ -992,7 +992,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
 // batch size (a frame's features must not depend on the batch it travels in).
 // 8 consumer waves (cout group w & 3, pixel half w >> 2: blocks 0..6 / 7..12; waves w and w + 4 share a SIMD) + 4 loader waves.
 // ------------------------------------------------------------------------------------------------
-template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS>
+template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST>
 __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int PW = IW + 2, PP = (TR + 2) * PW, PPT = NI * PP;     // padded positions per panel / per tile
@@ -1005,7 +1005,8 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
     // fixed cost of ~500 cycles (barrier skew, first fragments' LDS latency), so longer steps spend less of their time on it
     static_assert(TPS == 1 || TPS == 3, "one tap or one kernel row per step");
     constexpr int SPC = 9 / TPS;                                      // steps per chunk
-    constexpr int WPASS = TPS * BC / 32, WSTAGE = TPS * BC * 128, NSTAGE = (TPS == 1) ? 3 : 2, D = NSTAGE - 1;
+    constexpr int WPASS = TPS * BC / 32, WSTAGE = TPS * BC * 128, NSTAGE = NST, D = NSTAGE - 1;
+    static_assert(D >= 1 && D <= 3, "1 to 3 weight stages in flight");
     constexpr int WRING = 2 * XBUF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #if defined(R50_STAMP)
@@ -1067,7 +1068,7 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
         // PREVIOUS chunk, and this loader runs at most D = 2 steps ahead of the consumers)
         // (TPS = 3: the three steps of a chunk; the loader is one step ahead, so step 0 of a chunk may still overlap the previous chunk's
         // last step: passes go beside steps 1 and 2)
-        constexpr int XS0 = (TPS == 1) ? 2 : 1, XPS = (TPS == 1) ? 2 : (XPASS + 1) / 2;     // first step that carries passes, passes per step
+        constexpr int XS0 = D, XPS = (XPASS + (SPC - XS0) - 1) / (SPC - XS0);     // first step that carries passes, passes per step
         auto xp_lo = [&](int s) { return s < XS0 ? XPASS : (XPS * (s - XS0) < XPASS ? XPS * (s - XS0) : XPASS); };
         auto xp_hi = [&](int s) { return s < XS0 ? XPASS : (XPS * (s - XS0 + 1) < XPASS ? XPS * (s - XS0 + 1) : XPASS); };
         static_assert(XPS * (SPC - XS0) >= XPASS, "the chunk's steps carry all input passes");
@@ -1105,25 +1106,32 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                 }
             }
         };
-        static_assert(WPASS + XPS <= 63, "vmcnt is 6 bits");
-        auto wait_younger = [&](int n) {          // all but the n youngest vector-memory operations of this wave are complete
-            if (n <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+        static_assert((D - 1) * (WPASS + XPS) <= 63 && D * WPASS <= 63, "vmcnt is 6 bits");
+        // all but the n youngest vector-memory operations of this wave are complete; n = the operations of the D - 1 steps after the one
+        // that must have landed: (D - 1) * WPASS + 0 .. (D - 1) * XPS input passes (or fewer steps at the end of the stream)
+        auto wait_younger = [&](int n) {
             bool done = false;
 #pragma unroll
-            for (int e = 0; e <= XPS; ++e)
-                if (!done && n == WPASS + e) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPASS + e) : "memory"); done = true; }
+            for (int e = 0; e <= (D - 1) * (WPASS + XPS); ++e)
+                if (!done && n == e) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(e) : "memory"); done = true; }
             if (!done) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        };
+        auto younger_of = [&](int g) {            // operations of steps g + 2 .. g + D (issued after step g + 1's)
+            int n = 0;
+#pragma unroll
+            for (int i = 2; i <= D; ++i) n += ops_of(g + i);
+            return n;
         };
 #pragma unroll
         for (int g0 = 0; g0 < D; ++g0)
             if (g0 < total) stage_issue(g0);
-        wait_younger(D == 2 ? ops_of(1) : 0);     // step 0 (and the first chunk's input, issued before it) landed
+        wait_younger(younger_of(-1));             // step 0 (and the first chunk's input, issued before it) landed
         __builtin_amdgcn_s_barrier();
         R50_STAMP_DECL
         for (int g = 0; g < total; ++g) {
             if (g + D < total) stage_issue(g + D);
             R50_MARK(0)                           // DMA issue
-            wait_younger(D == 2 ? ops_of(g + 2) : 0);   // step g+1 landed (steps issued so far: .. g+D; with D = 1 it is the youngest)
+            wait_younger(younger_of(g));          // step g+1 landed (steps issued so far: .. g+D)
             R50_MARK(1)                           // wait landed
             __builtin_amdgcn_s_barrier();
             R50_MARK(2)                           // barrier

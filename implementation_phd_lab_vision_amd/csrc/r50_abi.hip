@@ -403,12 +403,12 @@ bool is_xres_shape(const ConvArgs& a) {
           a.x_cstride == a.Cin && a.y_cstride == a.Cout && a.Ktot == 9 * a.Cin && a.et != 2)) return false;
     return (a.H == 14 && a.Cin == 256) || (a.H == 7 && a.Cin == 512) || (a.H == 28 && a.Cin == 128);
 }
-template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS>
+template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST>
 hipError_t launch_conv3x3_xres_t(ConvArgs a, hipStream_t s) {
     constexpr int PPT = NI * (TR + 2) * (IW + 2), XBUF = (PPT + 31) / 32 * 32 * 128;
-    constexpr size_t lds = 2 * (size_t)XBUF + (TPS == 1 ? 3 : 2) * (size_t)TPS * BC * 128;
+    constexpr size_t lds = 2 * (size_t)XBUF + NST * (size_t)TPS * BC * 128;
     static_assert(lds <= 163840, "LDS budget");
-    auto kern = conv3x3_xres_kernel<ET, BC, NI, TR, IW, IH, TPS>;
+    auto kern = conv3x3_xres_kernel<ET, BC, NI, TR, IW, IH, TPS, NST>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (g_num_cus == 0) {
@@ -430,10 +430,12 @@ hipError_t launch_conv3x3_xres(const ConvArgs& a, hipStream_t s) {
     // (bench.py, same box, two rounds each): generic tuned tile 82.2-82.5 k frames/s; this 83.1-83.2 k; 256 couts per tile (112
     // accumulator registers, spills outside the loop) 83.1-83.2 k; a whole kernel row per step (TPS = 3, ring of two 48-KB stages) 82.0 k.
     static const int var = [] { const char* v = std::getenv("R50_XRES_VARIANT"); return v ? std::atoi(v) : 0; }();    // A/B knob
-    if (a.H == 14) return var == 1 ? launch_conv3x3_xres_t<ET, 256, 1, 14, 14, 14, 1>(a, s)
-                        : var == 3 ? launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 3>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1>(a, s);
-    if (a.H == 7) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1>(a, s);
-    return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1>(a, s);
+    const bool deep = (var == 4);                  // ring of 4 weight stages (3 in flight) instead of 3
+    if (a.H == 14) return var == 1 ? launch_conv3x3_xres_t<ET, 256, 1, 14, 14, 14, 1, 3>(a, s)
+                        : var == 3 ? launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 3, 2>(a, s)
+                        : deep ? launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 4>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3>(a, s);
+    if (a.H == 7) return deep ? launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 4>(a, s) : launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 3>(a, s);
+    return deep ? launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 4>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3>(a, s);
 }
 
 // tiles a launch of tile id `tile` would have (0 if the id does not divide this Cout)

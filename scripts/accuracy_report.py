@@ -1,4 +1,5 @@
-"""Feature accuracy of the four precisions vs the oracle views (8 seeded frames). Run on the GPU box."""
+"""Feature accuracy of the five precisions vs the oracle views (8 seeded frames), for both synthetic weight families. Run on the GPU box.
+usage: python scripts/accuracy_report.py [uniform|trained]"""
 import sys, torch
 sys.path.insert(0, '.')
 from implementation_phd_lab_vision_amd import _lib
@@ -6,7 +7,9 @@ from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
 from implementation_phd_lab_vision_amd.weights import synthetic_frames, synthetic_state_dict
 from oracle import resnet50_oracle as O
 _lib.build_library()
-sd = synthetic_state_dict(0); x = synthetic_frames(8, seed=1234)
+family = sys.argv[1] if len(sys.argv) > 1 else 'uniform'
+print(f'== weight family: {family}')
+sd = synthetic_state_dict(0, family=family); x = synthetic_frames(8, seed=1234)
 f64 = O.forward_reference(sd, x, dtype=torch.float64).flatten(1)
 f32 = O.forward_reference(sd, x).flatten(1)
 emu = O.forward_bf16_emulated(sd, x, fused_ds=True)
@@ -23,6 +26,9 @@ for prec in ("bf16", "fp16", "bf16w2", "fp32x"):
           (float(O.per_row_rel_l2(f, f64).max()), float((f.double() - f64).abs().max()), float(O.per_row_rel_l2(f, emu).max())))
     bb.close()
 bb = ResNet50Backbone(state_dict=sd, max_batch=8, precision="fp8").to("cuda:0").eval()       # calibrated on 8 other synthetic frames
+if family != "uniform":
+    from implementation_phd_lab_vision_amd.weights import synthetic_frames as _sf
+    bb.calibrate_fp8(frames=_sf(8, seed=4321).to("cuda:0"))
 f = bb(x.to("cuda:0")).flatten(1).cpu()
 emu8 = O.forward_fp8_emulated(sd, x, bb.fp8_scales)
 print("oracle fp8-emu vs fp64   : max per-frame rel-L2 %.3e" % float(O.per_row_rel_l2(emu8, f64).max()))
