@@ -148,6 +148,8 @@ struct ConvArgs {
     int y_cstride;        // channels per pixel of Y / residual (Cout; 2*Cout in split mode)
     int et;               // element type of operands / activations: 0 = bf16, 1 = fp16 (host-side dispatch only)
     float oscale, rscale; // fp8 only: y = fp8(act(acc * oscale + residual * rscale)); bias arrives divided by the dequantisation scale
+    float q_inv;          // 16-bit igemm_ws_kernel only, > 0: the output is written as e4m3, fp8(value16 * q_inv) with value16 the 16-bit result
+                          // (the hand-over of layer1's output to the fp8 stack folded into layer1.2.conv3's epilogue; y_bytes = M * Cout then)
     // Second K source of a 1x1 conv (igemm_ws_kernel only): K = [x (Cin = 64*cc1 channels) | x2 (the rest of cin_chunks)], the
     // second one read at stride2 from its own tensor -- conv3 and the downsample conv of a stage's first bottleneck as ONE GEMM
     // against [W3 | Wd].  x2 == nullptr: ordinary conv (cc1 is then huge).
@@ -650,8 +652,9 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
         const int wave_c = wave / CWP, wave_p = wave % CWP;
         const int fr = lane & 15, fq = lane >> 4;
         const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+        // (with a quantising epilogue y_bytes counts e4m3 bytes; the residual is still 16-bit)
         const __amdgpu_buffer_rsrc_t rsrc_r =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, a.res ? a.y_bytes : 0u, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, a.res ? (a.q_inv > 0.f ? 2u * a.y_bytes : a.y_bytes) : 0u, 0x00020000);
         f32x4 acc[MR][NR];
         constexpr bool PREFETCH_RES = !BIG;
         u32x4 res_reg[PREFETCH_RES ? MR / 2 : 1][PREFETCH_RES ? NR : 1];
@@ -780,6 +783,15 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
                     if (a.relu) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) out[e] = relu_bf16x2(out[e]);
+                    }
+                    if constexpr (ET != 2) {
+                        if (a.q_inv > 0.f) {             // (uniform) quantise the 16-bit result exactly as quant_to_fp8_kernel would: 8 bytes per lane
+                            const u32x2 o8 = (u32x2){
+                                pack4_fp8(unpack_lo_e<ET>(out[0]) * a.q_inv, unpack_hi_e<ET>(out[0]) * a.q_inv, unpack_lo_e<ET>(out[1]) * a.q_inv, unpack_hi_e<ET>(out[1]) * a.q_inv),
+                                pack4_fp8(unpack_lo_e<ET>(out[2]) * a.q_inv, unpack_hi_e<ET>(out[2]) * a.q_inv, unpack_lo_e<ET>(out[3]) * a.q_inv, unpack_hi_e<ET>(out[3]) * a.q_inv)};
+                            __builtin_amdgcn_raw_buffer_store_b64(o8, rsrc_y, voff >> 1, 0, 0);
+                            continue;
+                        }
                     }
 #if defined(R50_ABLATE_WS) && (R50_ABLATE_WS & 4)
                     if (out[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, 0);

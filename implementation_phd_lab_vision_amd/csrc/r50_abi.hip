@@ -66,6 +66,7 @@ struct r50_handle {
     __bf16* cat_w[4] = {nullptr, nullptr, nullptr, nullptr};      // per stage: (cout, cmid + cin) = [W3 | Wd], device
     float* cat_bias[4] = {nullptr, nullptr, nullptr, nullptr};    // b3 + bd (fp32)
     int fuse_tail = 1;                  // bf16 mode, layer1: conv3 + identity + ReLU + the next block's conv1 in one kernel
+    int fuse_fp8_handover = 1;          // fp8 mode: quantise layer1's output in layer1.2.conv3's epilogue instead of in a pass of its own
     int fuse_tail3 = 1;                 // layer3.1-.4: conv3 + identity + ReLU chained with the next block's conv1 through LDS (bneck_tail3_kernel)
     __bf16* tail3_wp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per layer3 block b: [W3(b) | W1(b+1)] in the kernel's fragment order
     int n_streams = 1;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
@@ -587,7 +588,7 @@ int fill_conv_args(ConvArgs& a, const void* x, int n, int h, int w, int cin, con
     a.div_wo = make_fast_div((unsigned)a.Wo);
     a.div_ctiles = FastDiv{0u, 0u};
     a.et = 0;
-    a.oscale = 1.0f; a.rscale = 1.0f;
+    a.oscale = 1.0f; a.rscale = 1.0f; a.q_inv = 0.0f;
     a.x2 = nullptr; a.H2 = 0; a.W2 = 0; a.stride2 = 1; a.x2_cstride = 0; a.cc1 = 1 << 30; a.x2_records = 0u;
 #if defined(R50_STAMP)
     a.dbg = nullptr;
@@ -723,8 +724,9 @@ hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const
     return hipGetLastError();
 }
 
+// q_inv > 0: write the output as e4m3 = fp8(16-bit result * q_inv) (role-specialised tiles only; *q_done reports whether that happened)
 int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, int ww, const __bf16* res,
-             __bf16* y, int relu, hipStream_t s, int* ho, int* wo) {
+             __bf16* y, int relu, hipStream_t s, int* ho, int* wo, float q_inv = 0.f, bool* q_done = nullptr) {
     ConvArgs a;
     const bool split = (h->precision == R50_PREC_FP32X);
     const bool w2 = (h->precision == R50_PREC_BF16W2);
@@ -734,8 +736,17 @@ int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, 
     EvRec r{};
     const double flops = 2.0 * a.M * (double)a.Cout * L.ks * L.ks * L.cin;       // algorithmic (not the 3x of split mode)
     const double bytes = 2.0 * ((double)n * hh * ww * L.cin + (double)a.M * a.Cout * (res ? 2 : 1) + (double)a.Cout * L.ks * L.ks * L.cin);
+    int tile = h->tile_override;
+    if (q_done) *q_done = false;
+    if (q_inv > 0.f && !split && !w2 && tile == 0) {
+        const int t = auto_tile(a);
+        if ((t & kWsBit) && t != kTileC64 && t != kTileXres) {      // the quantising epilogue lives in igemm_ws_kernel
+            tile = t; a.q_inv = q_inv; a.y_bytes = (unsigned)((long long)a.M * a.y_cstride);
+            if (q_done) *q_done = true;
+        }
+    }
     prof_begin(h, s, r, PC_IGEMM, flops, bytes, (int)(&L - &h->convs[0]));
-    hipError_t e = launch_igemm(a, h->tile_override, s, split);
+    hipError_t e = launch_igemm(a, tile, s, split);
     prof_end(h, s, r);
     if (e != hipSuccess) return fail(h, R50_ERR_HIP, "igemm launch (" + L.conv_key + "): " + hipGetErrorString(e));
     *ho = a.Ho; *wo = a.Wo;
@@ -915,7 +926,7 @@ int run_conv_fp8(r50_handle* h, const ConvLayer& L, const void* x, int n, int hh
 }
 
 // buf[cur] holds layer1's output (n,56,56,256) as 16-bit elements: quantise it, run layer2-4 in fp8, pool.
-int run_fp8_part(r50_handle* h, __bf16* const* buf, int cur, int n, float* out, hipStream_t s) {
+int run_fp8_part(r50_handle* h, __bf16* const* buf, int cur, int n, float* out, hipStream_t s, bool already_fp8 = false) {
     if ((int)h->fp8_scales.size() != R50_FP8_NUM_SCALES)
         return fail(h, R50_ERR_STATE, "fp8 mode: call r50_set_fp8_scales (activation scales) before the first forward");
     const float* sc = h->fp8_scales.data();
@@ -923,7 +934,7 @@ int run_fp8_part(r50_handle* h, __bf16* const* buf, int cur, int n, float* out, 
     float s_in = sc[k++];
     EvRec r{};
     int nxt = (cur + 1) % 5;
-    {
+    if (!already_fp8) {
         const long long n4 = (long long)n * 56 * 56 * 256 / 4;
         prof_begin(h, s, r, PC_MAXPOOL, 0, (double)n4 * 12);
         hipLaunchKernelGGL(quant_to_fp8_kernel<0>, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 256 * 64)), dim3(256), 0, s,
@@ -1049,12 +1060,13 @@ after_pool:
 
     int cur = 1, hh = 56, ww = 56;
     int pre_t1 = stem_c1 ? 2 : -1;      // buffer that already holds the coming block's conv1 output (fused tail / stem), or -1
+    bool layer1_out_fp8 = false;        // fp8 mode: layer1's output was written as e4m3 by its last conv's epilogue
     size_t li = 1;
     for (int si = 0; si < 4; ++si) {
         const int blocks = kStages[si][1];
         if (si == 1 && h->precision == R50_PREC_FP8) {
             if (tap) return fail(h, R50_ERR_INVALID, "fp8 mode: activations beyond layer1 are e4m3 tensors, taps stop at layer1.2");
-            return run_fp8_part(h, buf, cur, n, out, s);
+            return run_fp8_part(h, buf, cur, n, out, s, layer1_out_fp8);
         }
         for (int b = 0; b < blocks; ++b) {
             int fr[4], nf = 0;
@@ -1150,7 +1162,12 @@ after_pool:
                 if (rc) return rc;
                 h3 = h2; w3 = w2;
             } else {
-                rc = run_conv(h, c3, buf[fr[1]], n, h2, w2, idn, buf[fr[3]], 1, s, &h3, &w3);
+                // fp8 mode, layer1's last conv: the hand-over to the fp8 stack (quantisation with the first activation scale) is folded into
+                // this conv's epilogue -- the 16-bit tensor is neither written nor read back (unless a tap asks for it)
+                const bool handover = (h->precision == R50_PREC_FP8 && h->fuse_fp8_handover && si == 0 && b == blocks - 1 && !tap &&
+                                       (int)h->fp8_scales.size() == R50_FP8_NUM_SCALES);
+                rc = run_conv(h, c3, buf[fr[1]], n, h2, w2, idn, buf[fr[3]], 1, s, &h3, &w3, handover ? 1.0f / h->fp8_scales[0] : 0.f,
+                              handover ? &layer1_out_fp8 : nullptr);
                 if (rc) return rc;
             }
             cur = fr[3]; hh = h3; ww = w3;
@@ -1511,6 +1528,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "fused_stem") h->fused_stem = value ? 1 : 0;
     else if (k == "fuse_tail") h->fuse_tail = value ? 1 : 0;
     else if (k == "fuse_tail3") h->fuse_tail3 = value ? 1 : 0;
+    else if (k == "fuse_fp8_handover") h->fuse_fp8_handover = value ? 1 : 0;
     else if (k == "fuse_stem_c1") h->fuse_stem_c1 = value ? 1 : 0;
     else if (k == "fuse_ds_cat") h->fuse_ds_cat = value ? 1 : 0;
     else if (k == "stem_strip") {          // process-wide (the launcher is shared by the handle and the r50_op_* hooks)
@@ -1533,6 +1551,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "fused_stem") *value = h->fused_stem;
     else if (k == "fuse_tail") *value = h->fuse_tail;
     else if (k == "fuse_tail3") *value = h->fuse_tail3;
+    else if (k == "fuse_fp8_handover") *value = h->fuse_fp8_handover;
     else if (k == "fuse_stem_c1") *value = h->fuse_stem_c1;
     else if (k == "fuse_ds_cat") *value = h->fuse_ds_cat;
     else if (k == "stem_strip") *value = g_stem_strip;

@@ -148,3 +148,29 @@ def test_device_producer_augment_variants(tmp_path, lib_built):
                 assert rel < 2e-2, (sid, row, rel)
             else:
                 assert torch.equal(a, b), (sid, row, meta["aug"])
+
+
+def test_cli_device_producer_flag_end_to_end(tmp_path, lib_built, capsys):
+    """The CLI itself with --device-producer (and --augment): same files as the host-producer CLI run for the variants whose frames are
+    bit-defined (orig / hflip / trev), cjitter rows finite."""
+    from implementation_phd_lab_vision_amd.preprocess_resnet_features import main
+    common = ["--root", "unused", "--synthetic-clips", "4", "--synthetic-decoded", "--seq-len", "2", "--batch-size", "3", "--num-workers", "0",
+              "--shard-size", "4", "--shuffle-pool", "4", "--device", "cuda", "--max-batch", "16", "--synthetic-weights"]
+    a, b = tmp_path / "host", tmp_path / "dev"
+    main(common + ["--out", str(a)])
+    main(common + ["--out", str(b), "--device-producer", "--resize-mode", "fixed"])
+    assert "Producer   : on the device" in capsys.readouterr().out
+    from tests.helpers import assert_same_feature_cache
+    for name in ("index.pt", "shard_00000.pt"):
+        x, y = torch.load(a / name, weights_only=True), torch.load(b / name, weights_only=True)
+        if name == "index.pt":
+            assert x == y
+        else:
+            for key in ("feats", "joints3d", "joints2d", "K"):
+                assert torch.equal(x[key], y[key]), key
+            assert all(torch.equal(m1["box"], m2["box"]) for m1, m2 in zip(x["meta"], y["meta"]))
+    c = tmp_path / "aug"
+    main(common + ["--out", str(c), "--device-producer", "--resize-mode", "fixed", "--augment"])
+    sh = torch.load(c / "shard_00000.pt", weights_only=True)
+    assert sh["feats"].shape[0] == 16 and torch.isfinite(sh["feats"]).all() and [m["aug"] for m in sh["meta"][:4]] == ["orig", "cjitter", "hflip", "trev"]
+    assert torch.equal(sh["feats"][3], sh["feats"][0].flip(0))          # trev = orig in reverse frame order

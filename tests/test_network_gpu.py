@@ -428,3 +428,20 @@ def test_layer3_chained_tail_is_bit_identical_to_separate_launches(setup):
     finally:
         bb.set_option("fuse_tail3", 1)
     assert torch.equal(fused, plain)
+
+
+def test_fp8_handover_in_the_conv_epilogue_is_bit_identical(setup_fp8):
+    """fp8 mode: layer1's 16-bit output is quantised to e4m3 inside layer1.2.conv3's epilogue (same rounding sequence: 16-bit result,
+    then x 1/scale, then e4m3) -- same features as with the separate quantisation pass, at batch sizes on both sides of the tile rule."""
+    from implementation_phd_lab_vision_amd.weights import synthetic_frames
+    bb, _sd, _x = setup_fp8
+    assert bb.get_option("fuse_fp8_handover") == 1
+    for n in (3, 8):
+        xs = synthetic_frames(n, seed=40 + n).to("cuda:0")
+        fused = bb.features(xs).clone()
+        bb.set_option("fuse_fp8_handover", 0)
+        try:
+            plain = bb.features(xs).clone()
+        finally:
+            bb.set_option("fuse_fp8_handover", 1)
+        assert torch.equal(fused, plain), n
