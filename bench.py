@@ -199,6 +199,7 @@ def main() -> None:
     ap.add_argument("--no-stem-c1", action="store_true", help="A/B: layer1.0.conv1 as its own igemm launch instead of inside the stem kernel")
     ap.add_argument("--no-ds-cat", action="store_true", help="A/B: downsample conv and conv3 of layer2.0 / 3.0 / 4.0 as separate launches")
     ap.add_argument("--no-overlap-ds", action="store_true", help="A/B: downsample convs on the main stream")
+    ap.add_argument("--inplace", action="store_true", help="A/B: plain-identity blocks write their output over their input (same bits; measured: no gain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat", type=float, default=1.0,
                     help="seconds of untimed pre-heat of the same step before the timed region (independent of --warmup)")
@@ -256,6 +257,8 @@ def main() -> None:
         bb.set_option("fuse_tail", 0)
     if args.no_overlap_ds:
         bb.set_option("overlap_ds", 0)
+    if args.inplace:
+        bb.set_option("inplace_out", 1)
     x = synthetic_frames(args.batch, seed=1234 + rank).to(dev)          # random data, resident in HBM
     run = bb.features
     if args.input == "u8":

@@ -1004,7 +1004,13 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
 // batch size (a frame's features must not depend on the batch it travels in).
 // 8 consumer waves (cout group w & 3, pixel half w >> 2: blocks 0..6 / 7..12; waves w and w + 4 share a SIMD) + 4 loader waves.
 // ------------------------------------------------------------------------------------------------
-template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST>
+// Diagnostic ablations (scripts/build_variant.sh -DXRES_ABL=mask; timing only, results are wrong; consumer bits act on SCHED 1 only):
+// 1 = pixel-fragment addresses without the per-tap arithmetic, 4 = no stores, 8 = no MFMAs (reads stay live), 16 = no pixel-fragment
+// reads, 32 = every LDS-DMA zero-fills (issued, no L2 traffic), 64 = the loaders issue no DMA at all (barriers only), 128 = no per-step barrier
+#ifndef XRES_ABL
+#define XRES_ABL 0
+#endif
+template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST, int SCHED = 0>
 __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int PW = IW + 2, PP = (TR + 2) * PW, PPT = NI * PP;     // padded positions per panel / per tile
@@ -1018,7 +1024,7 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
     static_assert(TPS == 1 || TPS == 3, "one tap or one kernel row per step");
     constexpr int SPC = 9 / TPS;                                      // steps per chunk
     constexpr int WPASS = TPS * BC / 32, WSTAGE = TPS * BC * 128, NSTAGE = NST, D = NSTAGE - 1;
-    static_assert(D >= 1 && D <= 3, "1 to 3 weight stages in flight");
+    static_assert(D >= 1 && D <= 5, "1 to 5 weight stages in flight");
     constexpr int WRING = 2 * XBUF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #if defined(R50_STAMP)
@@ -1051,6 +1057,7 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                 const int tt = row / BC, rho = row - tt * BC;
                 const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
                 w_voff[i] = (unsigned)((c0 + cl) * a.Ktot + tt * a.Cin + (slot ^ (rho & 7)) * 8) * 2u;
+                if (XRES_ABL & 32) w_voff[i] = kOobOffset;
             }
         };
         auto decode_x = [&](int tile) {           // source offsets of the padded positions of `tile` (out of range = zero border)
@@ -1064,6 +1071,7 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                 const int n = n0 + panel, y = band * TR + rr - 1, x = cc - 1;
                 const bool ok = q < PPT && tile < n_tiles && n < a.N && (unsigned)y < (unsigned)IH && (unsigned)x < (unsigned)IW;
                 x_voff[i] = ok ? (unsigned)(((n * IH + y) * IW + x) * a.Cin + (slot ^ (q & 7)) * 8) * 2u : kOobOffset;
+                if (XRES_ABL & 32) x_voff[i] = kOobOffset;
             }
         };
         // stream position of the NEXT step to issue, and of the input chunk that is fetched beside it (one chunk ahead)
@@ -1074,13 +1082,15 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < XPASS; ++i)
                 if (i >= p0 && i < p1)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + x_par * XBUF + i * 4096 + lw * 1024), 16, x_voff[i], xofs, 0, 0);
+                    if (!(XRES_ABL & 64)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + x_par * XBUF + i * 4096 + lw * 1024), 16, x_voff[i], xofs, 0, 0);
         };
         // X passes issued beside tap s of a chunk: taps 2..8 carry two passes each (the buffer being refilled was read until tap 8 of the
         // PREVIOUS chunk, and this loader runs at most D = 2 steps ahead of the consumers)
         // (TPS = 3: the three steps of a chunk; the loader is one step ahead, so step 0 of a chunk may still overlap the previous chunk's
         // last step: passes go beside steps 1 and 2)
-        constexpr int XS0 = D, XPS = (XPASS + (SPC - XS0) - 1) / (SPC - XS0);     // first step that carries passes, passes per step
+        // (SCHED 1: the consumers pass a step's barrier in the MIDDLE of that step and go on reading its input fragments, so the refill
+        // of the other buffer starts one step later)
+        constexpr int XS0 = D + (SCHED ? 1 : 0), XPS = (XPASS + (SPC - XS0) - 1) / (SPC - XS0);     // first step that carries passes, passes per step
         auto xp_lo = [&](int s) { return s < XS0 ? XPASS : (XPS * (s - XS0) < XPASS ? XPS * (s - XS0) : XPASS); };
         auto xp_hi = [&](int s) { return s < XS0 ? XPASS : (XPS * (s - XS0 + 1) < XPASS ? XPS * (s - XS0 + 1) : XPASS); };
         static_assert(XPS * (SPC - XS0) >= XPASS, "the chunk's steps carry all input passes");
@@ -1104,7 +1114,7 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
             char* sbase = smem + WRING + i_buf * WSTAGE + lw * 1024;
 #pragma unroll
             for (int i = 0; i < WPASS; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LDS_AS void*)(sbase + i * 4096), 16, w_voff[i], wofs, 0, 0);
+                if (!(XRES_ABL & 64)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LDS_AS void*)(sbase + i * 4096), 16, w_voff[i], wofs, 0, 0);
             const bool has_next_chunk = (g / SPC) + 1 < my_tiles * cch;
             if (has_next_chunk && i_s >= XS0) x_issue(xp_lo(i_s), xp_hi(i_s));
             i_buf = (i_buf == NSTAGE - 1) ? 0 : i_buf + 1;
@@ -1145,7 +1155,7 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
             R50_MARK(0)                           // DMA issue
             wait_younger(younger_of(g));          // step g+1 landed (steps issued so far: .. g+D)
             R50_MARK(1)                           // wait landed
-            __builtin_amdgcn_s_barrier();
+            if (!(XRES_ABL & 128)) __builtin_amdgcn_s_barrier();
             R50_MARK(2)                           // barrier
         }
         R50_STAMP_FLUSH(12)
@@ -1276,9 +1286,153 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
 #endif
             R50_STAMP_FLUSH(12)
         };
+        // SCHED 1: the step's barrier sits in the MIDDLE of the step, and the LDS reads a step starts with -- its weight fragments and its
+        // first PD pixel fragments -- are issued behind the barrier of the step BEFORE it (which is what guarantees that stage has landed),
+        // under that step's remaining MFMAs.  In the schedule above every wave leaves the barrier with nothing in registers: all eight
+        // consumers burst 7 reads each into the LDS at once and every SIMD idles for one loaded LDS round trip (~250 cycles of a
+        // ~1,700-cycle step), then idles again at the step's end while the slowest wave and the loaders arrive.  Here a step's first MFMA
+        // issues straight after the previous step's last one, and a wave that waits at the barrier still has half a step of MFMAs queued
+        // behind it.  Same MFMA order per accumulator: bit-identical results.
+        auto run_steps_mid = [&](auto nrw_c) {
+            constexpr int NRW = decltype(nrw_c)::value, NS = 2 * NRW, PD = 3;
+            constexpr int NXT = 2 * MR + PD;                            // reads of the next step issued behind the barrier
+            constexpr int TB = NS - NXT;                                // slots in front of the barrier
+            static_assert(TPS == 1 && MR <= 2 && TB >= 1 && TB + PD <= NS, "mid-step barrier: one tap per step, both K halves of the weights in registers");
+            int tile = first, c = 0, s = 0, c_buf = 0, x_par = 0;
+            bf16x8 wA[2 * MR], xA[PD], wB[2 * MR], xB[PD];
+            int qa[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) qa[j] = q0[j] * 128 + ((fq ^ (q0[j] & 7)) << 4);
+            auto xread = [&](const char* xb, int toff, int t) {
+                if constexpr (XRES_ABL & 16) { return __builtin_bit_cast(bf16x8, (u32x4){(unsigned)toff, 1u, 2u, (unsigned)t}); }
+                else if constexpr (XRES_ABL & 1) { return *reinterpret_cast<const bf16x8*>(xb + (qa[t % NRW] ^ (t >= NRW ? 64 : 0))); }
+                else {
+                const int row = q0[t % NRW] + toff;
+                return *reinterpret_cast<const bf16x8*>(xb + row * 128 + ((((t >= NRW ? 4 : 0) + fq) ^ (row & 7)) << 4));
+                }
+            };
+            auto wread = [&](const char* wb, int i) {                   // i < MR: K half 0 of cout block i; else K half 1 of block i - MR
+                return *reinterpret_cast<const bf16x8*>(wb + (i % MR) * 2048 + (i < MR ? w_ph0 : (w_ph0 ^ 64)));
+            };
+            auto init_acc = [&](int tile) {
+                const int c0 = (tile % nct) * BC;
+#pragma unroll
+                for (int t = 0; t < MR / 2; ++t) {
+                    const f32x4 b_lo = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t);
+                    const f32x4 b_hi = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t + 4);
+#pragma unroll
+                    for (int j = 0; j < NRW; ++j) { acc[2 * t][j] = b_lo; acc[2 * t + 1][j] = b_hi; }
+                }
+            };
+            auto epilogue = [&](int tile) {       // ReLU, 16-bit, one 16-B store per pixel and block pair
+                const int c0 = (tile % nct) * BC;
+                const int pt = tile / nct;
+                const int band = pt % NB, n0 = (pt / NB) * NI;
+#pragma unroll
+                for (int j = 0; j < NRW; ++j) {
+                    const int p = 16 * (7 * wave_p + j) + fr;
+                    const int pc = p < NPX ? p : NPX - 1;
+                    const int panel = pc / (TR * IW), rem = pc - panel * (TR * IW);
+                    const int r = rem / IW, cx = rem - r * IW;
+                    const int n = n0 + panel;
+                    const bool ok = p < NPX && n < a.N;
+                    const unsigned pix = (unsigned)((n * IH + band * TR + r) * IW + cx);
+#pragma unroll
+                    for (int t = 0; t < MR / 2; ++t) {
+                        const f32x4 lo = acc[2 * t][j], hi = acc[2 * t + 1][j];
+                        u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+                        if (a.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                        }
+                        const unsigned voff = ok ? (pix * (unsigned)a.Cout + (unsigned)(c0 + cout_lane + 32 * t)) * 2u : kOobOffset;
+                        if (!(XRES_ABL & 4) || o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff, 0, 0);
+                    }
+                }
+            };
+            // operands of step 0 (stage 0 and the first input chunk landed: the barrier in front of this call)
+            {
+                const char* wb = smem + WRING + w_row;
+#pragma unroll
+                for (int i = 0; i < 2 * MR; ++i) wA[i] = wread(wb, i);
+#pragma unroll
+                for (int t = 0; t < PD; ++t) xA[t] = xread(smem, 0, t);
+            }
+            init_acc(tile);
+            auto step = [&](bf16x8 (&wc)[2 * MR], bf16x8 (&xc)[PD], bf16x8 (&wn)[2 * MR], bf16x8 (&xn)[PD]) {
+                const int kh = (s >= 6) ? 2 : (s >= 3) ? 1 : 0, kw = s - 3 * kh;
+                const int toff = kh * PW + kw;
+                const char* xb = smem + x_par * XBUF;
+                int ns = s + 1, nx_par = x_par;
+                if (ns == SPC) { ns = 0; nx_par ^= 1; }
+                const int nkh = (ns >= 6) ? 2 : (ns >= 3) ? 1 : 0, nkw = ns - 3 * nkh;
+                const int ntoff = nkh * PW + nkw;
+                const int nc_buf = (c_buf == NSTAGE - 1) ? 0 : c_buf + 1;
+                const char* nxb = smem + nx_par * XBUF;
+                const char* nwb = smem + WRING + nc_buf * WSTAGE + w_row;
+                bf16x8 x[NS];
+#pragma unroll
+                for (int t = 0; t < PD; ++t) x[t] = xc[t];
+                // ---- slots in front of the barrier
+#pragma unroll
+                for (int t = 0; t < TB; ++t) {
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) {
+                        if constexpr (XRES_ABL & 8) { asm volatile("" ::"v"(t >= NRW ? wc[MR + m] : wc[m]), "v"(x[t])); }
+                        else acc[m][t % NRW] = mfma_e<ET>(t >= NRW ? wc[MR + m] : wc[m], x[t], acc[m][t % NRW]);
+                    }
+                    x[t + PD] = xread(xb, toff, t + PD);
+                }
+#pragma unroll
+                for (int t = 0; t < TB; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(XRES_ABL & 128)) __builtin_amdgcn_s_barrier();    // the NEXT step's stage has landed; nobody reads the stage before this one any more
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- slots behind it, each with one read of the next step's operands
+#pragma unroll
+                for (int t = TB; t < NS; ++t) {
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) {
+                        if constexpr (XRES_ABL & 8) { asm volatile("" ::"v"(t >= NRW ? wc[MR + m] : wc[m]), "v"(x[t])); }
+                        else acc[m][t % NRW] = mfma_e<ET>(t >= NRW ? wc[MR + m] : wc[m], x[t], acc[m][t % NRW]);
+                    }
+                    if (t + PD < NS) x[t + PD] = xread(xb, toff, t + PD);
+                    const int r = t - TB;
+                    if (r < 2 * MR) wn[r] = wread(nwb, r);
+                    else xn[r - 2 * MR] = xread(nxb, ntoff, r - 2 * MR);
+                }
+#pragma unroll
+                for (int t = TB; t < NS; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);
+                    if (t + PD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- advance the stream position
+                c_buf = nc_buf; s = ns; x_par = nx_par;
+                if (ns == 0 && ++c == cch) {
+                    c = 0;
+                    epilogue(tile);
+                    tile += grid;
+                    if (tile < n_tiles) init_acc(tile);
+                }
+            };
+            for (int g = 0; g < total; g += 2) {
+                step(wA, xA, wB, xB);
+                if (g + 1 < total) step(wB, xB, wA, xA);
+            }
+        };
         __builtin_amdgcn_s_barrier();             // step 0 and the first input chunk landed
-        if (wave_p == 0) run_steps(std::integral_constant<int, 7>{});
-        else run_steps(std::integral_constant<int, 6>{});
+        if constexpr (SCHED == 1) {
+            if (wave_p == 0) run_steps_mid(std::integral_constant<int, 7>{});
+            else run_steps_mid(std::integral_constant<int, 6>{});
+        } else {
+            if (wave_p == 0) run_steps(std::integral_constant<int, 7>{});
+            else run_steps(std::integral_constant<int, 6>{});
+        }
     }
 #else
     (void)a;
@@ -1732,6 +1886,9 @@ __global__ void tail3_pack_kernel(const __bf16* __restrict__ w3, const __bf16* _
 #ifndef T3_PDB
 #define T3_PDB 7
 #endif
+#ifndef T3_XPRE           // cross-step prefetch of the first pixel fragments, bit mask: 1 = A0..A3, 2 = B0..B3, 4 = B3 -> next chunk's A0 (0 = every step opens with its own reads)
+#define T3_XPRE 0
+#endif
 template <int ET>
 __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1852,7 +2009,7 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
         // the wave's channels 32w .. 32w+31 of a chunk: slot w>>1, 16-B chunk 4(w&1) + fq of a pixel row (residual in, out_c out)
         const int c_frag = (w >> 1) * SLOT + x_frag + (((4 * (w & 1) + fq) ^ (fr & 7)) << 4);
         f32x4 accA[2][NR], accB[4][NR];
-        bf16x8 wA[4], wB[4];
+        bf16x8 wA[4], wB[4], xq[NR];                 // xq: pixel fragments requested for the coming step (T3_XPRE)
         // weight fragments of step gs (0..63 of a tile; the stream is the same for every tile), K half kk: wf[kk] (m = 0), wf[2 + kk] (m = 1)
         auto w_load_half = [&](int gs, bf16x8 (&wf)[4], int kk) {
             const int sofs = __builtin_amdgcn_readfirstlane((gs & 63) * 16384);
@@ -1867,15 +2024,22 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
         // the 256-register limit): the K = 32..63 fragment of pixel block j replaces the K = 0..31 one as soon as that block's MFMAs
         // are issued and is consumed 14 MFMAs later; then the fragments of step gs + 2 are requested into the registers this step
         // has released (order pinned with sched_group_barrier).
-        auto w_step = [&](auto pd, int gs, bf16x8 (&wf)[4], const char* xb, f32x4 (&acc0)[NR], f32x4 (&acc1)[NR]) {
+        // T3_XPRE (default 1): the first PD pixel fragments of a step are requested during the LAST slots of the step before it (which
+        // have no reads of their own left) wherever the next step's operand is already complete in LDS -- A0 -> A1 -> A2 -> A3 (t2 is
+        // resident), B0 -> B1 -> B2 -> B3 (out_c is complete behind barrier O) and B3 -> the next chunk's A0 -- so that with ONE consumer wave
+        // per SIMD a step no longer opens with an exposed LDS round trip (stamps: 696 cycles per A step for 448 of MFMA issue).
+        auto w_step = [&](auto pd, auto have_c, auto pdn_c, int gs, bf16x8 (&wf)[4], const char* xb, const char* xnb, f32x4 (&acc0)[NR],
+                          f32x4 (&acc1)[NR], bf16x8 (&xq)[NR]) {
             // 14 slots t = 7 kk + j, each one pixel fragment and two MFMAs; the fragment of slot t + PD is read when slot t issues.
             // One wave per SIMD sees ~190 cycles of LDS latency under this load, i.e. 6 slots; the A steps (accA and accB both live)
             // have registers for PD = 4, the B steps (accA dead) for 7.
-            constexpr int NS = 2 * NR, PD = decltype(pd)::value;
+            constexpr int NS = 2 * NR, PD = decltype(pd)::value, PDN = decltype(pdn_c)::value;
+            constexpr bool HAVE = decltype(have_c)::value;
+            static_assert(PDN <= PD, "the next step's first reads ride on this step's read-free slots");
             bf16x8 x[NS];
-            auto xread = [&](int t) { return *reinterpret_cast<const bf16x8*>(xb + x_frag + (t % NR) * 2048 + (t >= NR ? (fphys0 ^ 64) : fphys0)); };
+            auto xread = [&](const char* b, int t) { return *reinterpret_cast<const bf16x8*>(b + x_frag + (t % NR) * 2048 + (t >= NR ? (fphys0 ^ 64) : fphys0)); };
 #pragma unroll
-            for (int t = 0; t < PD; ++t) x[t] = xread(t);
+            for (int t = 0; t < PD; ++t) x[t] = HAVE ? xq[t] : xread(xb, t);
 #pragma unroll
             for (int t = 0; t < NS; ++t) {
                 const int j = t % NR, kk = t / NR;
@@ -1884,17 +2048,18 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
                 acc0[j] = mfma_e<ET>(wf[kk], x[t], acc0[j]);
                 acc1[j] = mfma_e<ET>(wf[2 + kk], x[t], acc1[j]);
                 }
-                if (t + PD < NS) x[t + PD] = xread(t + PD);
+                if (t + PD < NS) x[t + PD] = xread(xb, t + PD);
+                else if (t + PD - NS < PDN) xq[t + PD - NS] = xread(xnb, t + PD - NS);
                 // the K half this step has just finished with is requested for step gs + 2 at once (half a step earlier than at the
                 // step's end: the loads come from L2 while every other CU streams too, and one step of cover is not enough)
                 if (t == NR - 1) w_load_half(gs + 2, wf, 0);
             }
             w_load_half(gs + 2, wf, 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
+            if (!HAVE) __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
 #pragma unroll
             for (int t = 0; t < NS; ++t) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                if (t + PD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (t + PD < NS || t + PD - NS < PDN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 if (t == NR - 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
@@ -1924,10 +2089,17 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
                     for (int j = 0; j < NR; ++j) { accA[0][j] = lo; accA[1][j] = hi; }
                 }
                 // ---- A: 4 K-slots of W3[c] . t2 (no barriers: weights from this wave's registers, t2 resident)
-                w_step(std::integral_constant<int, T3_PDA>{}, c * 8 + 0, wA, smem + T2 + 0 * SLOT, accA[0], accA[1]);
-                w_step(std::integral_constant<int, T3_PDA>{}, c * 8 + 1, wB, smem + T2 + 1 * SLOT, accA[0], accA[1]);
-                w_step(std::integral_constant<int, T3_PDA>{}, c * 8 + 2, wA, smem + T2 + 2 * SLOT, accA[0], accA[1]);
-                w_step(std::integral_constant<int, T3_PDA>{}, c * 8 + 3, wB, smem + T2 + 3 * SLOT, accA[0], accA[1]);
+                {
+                    using PA = std::integral_constant<int, T3_PDA>;
+                    using NX = std::integral_constant<int, (T3_XPRE & 1) ? T3_PDA : 0>;
+                    using N0 = std::integral_constant<int, 0>;
+                    // (A0's fragments were requested by the previous chunk's B3, except at a tile's first chunk)
+                    if ((T3_XPRE & 4) && c > 0) w_step(PA{}, std::true_type{}, NX{}, c * 8 + 0, wA, smem + T2 + 0 * SLOT, smem + T2 + 1 * SLOT, accA[0], accA[1], xq);
+                    else w_step(PA{}, std::false_type{}, NX{}, c * 8 + 0, wA, smem + T2 + 0 * SLOT, smem + T2 + 1 * SLOT, accA[0], accA[1], xq);
+                    w_step(PA{}, std::integral_constant<bool, (T3_XPRE & 1) != 0>{}, NX{}, c * 8 + 1, wB, smem + T2 + 1 * SLOT, smem + T2 + 2 * SLOT, accA[0], accA[1], xq);
+                    w_step(PA{}, std::integral_constant<bool, (T3_XPRE & 1) != 0>{}, NX{}, c * 8 + 2, wA, smem + T2 + 2 * SLOT, smem + T2 + 3 * SLOT, accA[0], accA[1], xq);
+                    w_step(PA{}, std::integral_constant<bool, (T3_XPRE & 1) != 0>{}, N0{}, c * 8 + 3, wB, smem + T2 + 3 * SLOT, smem + T2, accA[0], accA[1], xq);
+                }
 #if defined(R50_STAMP)
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_nop 0" ::"v"(accA[1][NR - 1]), "v"(accA[0][NR - 1]) : "memory");   // the stamp waits for the last MFMAs
@@ -1960,10 +2132,19 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
                 __builtin_amdgcn_s_barrier();     // O(c)
                 R50_MARK(4)                       // barrier O
                 // ---- B: W1[:, c] . out_c, K-slot kb x cout half h (no barriers)
-                w_step(std::integral_constant<int, T3_PDB>{}, c * 8 + 4, wA, smem + OUTC + 0 * SLOT, accB[0], accB[1]);
-                w_step(std::integral_constant<int, T3_PDB>{}, c * 8 + 5, wB, smem + OUTC + 0 * SLOT, accB[2], accB[3]);
-                w_step(std::integral_constant<int, T3_PDB>{}, c * 8 + 6, wA, smem + OUTC + 1 * SLOT, accB[0], accB[1]);
-                w_step(std::integral_constant<int, T3_PDB>{}, c * 8 + 7, wB, smem + OUTC + 1 * SLOT, accB[2], accB[3]);
+                {
+                    using PB = std::integral_constant<int, T3_PDB>;
+                    using NX = std::integral_constant<int, (T3_XPRE & 2) ? T3_PDB : 0>;
+                    using NA = std::integral_constant<int, (T3_XPRE & 4) ? T3_PDA : 0>;
+                    using N0 = std::integral_constant<int, 0>;
+                    using HV = std::integral_constant<bool, (T3_XPRE & 2) != 0>;
+                    w_step(PB{}, std::false_type{}, NX{}, c * 8 + 4, wA, smem + OUTC + 0 * SLOT, smem + OUTC + 0 * SLOT, accB[0], accB[1], xq);
+                    w_step(PB{}, HV{}, NX{}, c * 8 + 5, wB, smem + OUTC + 0 * SLOT, smem + OUTC + 1 * SLOT, accB[2], accB[3], xq);
+                    w_step(PB{}, HV{}, NX{}, c * 8 + 6, wA, smem + OUTC + 1 * SLOT, smem + OUTC + 1 * SLOT, accB[0], accB[1], xq);
+                    // B3 -> the next chunk's A0 (t2 stays resident for the whole tile); nothing after a tile's last chunk
+                    if ((T3_XPRE & 4) && c + 1 < NCH) w_step(PB{}, HV{}, NA{}, c * 8 + 7, wB, smem + OUTC + 1 * SLOT, smem + T2, accB[2], accB[3], xq);
+                    else w_step(PB{}, HV{}, N0{}, c * 8 + 7, wB, smem + OUTC + 1 * SLOT, smem + T2, accB[2], accB[3], xq);
+                }
 #if defined(R50_STAMP)
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_nop 0" ::"v"(accB[3][NR - 1]), "v"(accB[2][NR - 1]), "v"(accB[1][NR - 1]), "v"(accB[0][NR - 1]) : "memory");

@@ -69,6 +69,7 @@ struct r50_handle {
     int fuse_fp8_handover = 1;          // fp8 mode: quantise layer1's output in layer1.2.conv3's epilogue instead of in a pass of its own
     int fuse_tail3 = 1;                 // layer3.1-.4: conv3 + identity + ReLU chained with the next block's conv1 through LDS (bneck_tail3_kernel)
     __bf16* tail3_wp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per layer3 block b: [W3(b) | W1(b+1)] in the kernel's fragment order
+    int inplace_out = 0;                // plain-identity blocks write their output over their input (same bits, fewer DRAM page switches)
     int n_streams = 1;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -300,6 +301,10 @@ FastDiv make_fast_div(unsigned d) {
 //   + 32: chip-sized persistent grid (tiles streamed through the LDS ring) instead of one tile per workgroup
 constexpr int kPersistBit = 32;
 int g_num_cus = 0;
+// Workgroups a persistent launch may put on the chip: the CU count, or R50_CU_CAP / the "cu_cap" option when several internal streams
+// share the chip (each stream's launches then take their share of the CUs and run beside the other streams' launches).
+int g_cu_cap = [] { const char* v = std::getenv("R50_CU_CAP"); return v ? std::atoi(v) : 0; }();
+int cu_budget(int device_cus) { return (g_cu_cap > 0 && g_cu_cap < device_cus) ? g_cu_cap : device_cus; }
 
 template <int ET, int BC, int BP, int WC, int WP, int NSTAGE, bool SPLIT = false>
 hipError_t launch_igemm_t(ConvArgs a, bool persistent, hipStream_t s) {
@@ -320,7 +325,7 @@ hipError_t launch_igemm_t(ConvArgs a, bool persistent, hipStream_t s) {
             int dev = 0;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-            g_num_cus = prop.multiProcessorCount;
+            g_num_cus = cu_budget(prop.multiProcessorCount);
         }
         // resident workgroups per CU (LDS / registers / wave slots).  No workgroup waits on another one,
         // so an optimistic answer only queues the surplus workgroups; it cannot deadlock.
@@ -366,7 +371,7 @@ hipError_t launch_igemm_ws_t(ConvArgs a, hipStream_t s) {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        g_num_cus = prop.multiProcessorCount;
+        g_num_cus = cu_budget(prop.multiProcessorCount);
     }
     int grid = a.n_blocks < g_num_cus ? a.n_blocks : g_num_cus;
     hipLaunchKernelGGL(kern, dim3(grid), dim3((CWC * CWP + NLOAD) * 64), lds, s, a);
@@ -389,7 +394,7 @@ hipError_t launch_conv3x3_c64(const ConvArgs& a, hipStream_t s) {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        g_num_cus = prop.multiProcessorCount;
+        g_num_cus = cu_budget(prop.multiProcessorCount);
     }
     const int tiles = a.N * 14;
     hipLaunchKernelGGL(conv3x3_c64_kernel<ET>, dim3(tiles < g_num_cus ? tiles : g_num_cus), dim3(512), lds, s, a);
@@ -404,19 +409,19 @@ bool is_xres_shape(const ConvArgs& a) {
           a.x_cstride == a.Cin && a.y_cstride == a.Cout && a.Ktot == 9 * a.Cin && a.et != 2)) return false;
     return (a.H == 14 && a.Cin == 256) || (a.H == 7 && a.Cin == 512) || (a.H == 28 && a.Cin == 128);
 }
-template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST>
+template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST, int SCHED = 0>
 hipError_t launch_conv3x3_xres_t(ConvArgs a, hipStream_t s) {
     constexpr int PPT = NI * (TR + 2) * (IW + 2), XBUF = (PPT + 31) / 32 * 32 * 128;
     constexpr size_t lds = 2 * (size_t)XBUF + NST * (size_t)TPS * BC * 128;
     static_assert(lds <= 163840, "LDS budget");
-    auto kern = conv3x3_xres_kernel<ET, BC, NI, TR, IW, IH, TPS, NST>;
+    auto kern = conv3x3_xres_kernel<ET, BC, NI, TR, IW, IH, TPS, NST, SCHED>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (g_num_cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        g_num_cus = prop.multiProcessorCount;
+        g_num_cus = cu_budget(prop.multiProcessorCount);
     }
     a.n_ctiles = a.Cout / BC;
     a.n_blocks = ((a.N + NI - 1) / NI) * (IH / TR) * a.n_ctiles;
@@ -424,14 +429,30 @@ hipError_t launch_conv3x3_xres_t(ConvArgs a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, s, a);
     return hipGetLastError();
 }
+int g_xres_variant = [] { const char* v = std::getenv("R50_XRES_VARIANT"); return v ? std::atoi(v) : 0; }();
 template <int ET>
 hipError_t launch_conv3x3_xres(const ConvArgs& a, hipStream_t s) {
     if (!is_xres_shape(a)) return hipErrorInvalidValue;
     // 14x14: 128 couts x one image x one tap per step (512 tiles = two full rounds at batch 256).  Measured in the network at batch 256
     // (bench.py, same box, two rounds each): generic tuned tile 82.2-82.5 k frames/s; this 83.1-83.2 k; 256 couts per tile (112
     // accumulator registers, spills outside the loop) 83.1-83.2 k; a whole kernel row per step (TPS = 3, ring of two 48-KB stages) 82.0 k.
-    static const int var = [] { const char* v = std::getenv("R50_XRES_VARIANT"); return v ? std::atoi(v) : 0; }();    // A/B knob
+    const int var = g_xres_variant;               // A/B knob (R50_XRES_VARIANT / option "xres_variant")
     const bool deep = (var == 4);                  // ring of 4 weight stages (3 in flight) instead of 3
+    if (var == 6) {                                // mid-step barrier schedule + deeper weight ring (5 / 4 / 5 stages: 4 / 3 / 4 in flight)
+        if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 5, 1>(a, s);
+        if (a.H == 7) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 4, 1>(a, s);
+        return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 5, 1>(a, s);
+    }
+    if (var == 7) {                                // end-of-step barrier, deeper ring
+        if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 5, 0>(a, s);
+        if (a.H == 7) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 4, 0>(a, s);
+        return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 5, 0>(a, s);
+    }
+    if (var == 5) {                                // mid-step barrier schedule (kernels.h, SCHED 1)
+        if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 1>(a, s);
+        if (a.H == 7) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 3, 1>(a, s);
+        return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3, 1>(a, s);
+    }
     if (a.H == 14) return var == 1 ? launch_conv3x3_xres_t<ET, 256, 1, 14, 14, 14, 1, 3>(a, s)
                         : var == 3 ? launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 3, 2>(a, s)
                         : deep ? launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 4>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3>(a, s);
@@ -647,7 +668,7 @@ hipError_t launch_bneck_tail(const void* y2, long long m, const void* w3, const 
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        g_num_cus = prop.multiProcessorCount;
+        g_num_cus = cu_budget(prop.multiProcessorCount);
     }
     // 4 waves per CU stream best (more waves lower the HBM rate); the downsample variant has 1.5x the MFMA work
     if (et == 1) {
@@ -669,7 +690,7 @@ hipError_t launch_bneck_tail2(const void* y2, long long m, const void* w3, const
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        g_num_cus = prop.multiProcessorCount;
+        g_num_cus = cu_budget(prop.multiProcessorCount);
     }
     const long long steps = (m + 15) / 16;
     const int grid = (int)std::min<long long>(steps, (long long)g_num_cus);
@@ -700,7 +721,7 @@ hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        g_num_cus = prop.multiProcessorCount;
+        g_num_cus = cu_budget(prop.multiProcessorCount);
     }
     Tail3Args a;
     a.y2 = (const __bf16*)y2; a.wp = (const __bf16*)wp; a.b3 = b3; a.res = (const __bf16*)res; a.out = (__bf16*)out;
@@ -830,7 +851,7 @@ hipError_t launch_stem_fused(const TIN* x, const void* wpk, const float* bias, v
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        g_num_cus = prop.multiProcessorCount;
+        g_num_cus = cu_budget(prop.multiProcessorCount);
     }
     if (g_stem_strip >= 0) {
         // strip version: a workgroup walks G consecutive pooled-row pairs of one image; G = the longest strip that still gives
@@ -1139,6 +1160,14 @@ after_pool:
                 idn = buf[fr[2]];
             }
             if (ds_side) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_ds_join, 0));   // conv3 needs the downsample output
+            // Plain-identity blocks write the block output IN PLACE over the block input: every element of the identity is read (by the
+            // lane / wave / workgroup that produces the output element at the same address) before that output element is stored, nobody
+            // else reads the block input any more (conv1 ran earlier), and a DRAM page that has just been read is written while it is
+            // still open -- a device add_ (read + write the same addresses) streams 9 % faster than a copy on this chip
+            // (profiles/r02_hbm_copy_probe.txt).
+            const bool inplace = h->inplace_out && !split && b > 0 && idn == buf[cur] && !cat_ds && !fuse_ds &&
+                                 !(h->precision == R50_PREC_FP8 && si == 0 && b == blocks - 1);      // (the fp8 hand-over writes 1-byte elements)
+            __bf16* const outb = inplace ? buf[cur] : buf[fr[3]];
             if (fuse) {
                 const long long m = (long long)n * h2 * w2;
                 EvRec rt{};
@@ -1147,18 +1176,18 @@ after_pool:
                                   (double)c3.cout * c3.cin * (fuse_ds ? 2 : 1) + (double)nx->cin * nx->cout),
                            (int)(&c3 - &h->convs[0]));
                 if (fuse3)
-                    e = launch_bneck_tail3(buf[fr[1]], m, h->tail3_wp[b], c3.bias, idn, buf[fr[3]], nx->bias, buf[fr[0]], s, et);
+                    e = launch_bneck_tail3(buf[fr[1]], m, h->tail3_wp[b], c3.bias, idn, outb, nx->bias, buf[fr[0]], s, et);
                 else if (fuse2)
-                    e = launch_bneck_tail2(buf[fr[1]], m, c3.w, c3.bias, idn, buf[fr[3]], nx->w, nx->bias, buf[fr[0]], s, et);
+                    e = launch_bneck_tail2(buf[fr[1]], m, c3.w, c3.bias, idn, outb, nx->w, nx->bias, buf[fr[0]], s, et);
                 else
                     e = launch_bneck_tail(buf[fr[1]], m, c3.w, c3.bias, fuse_ds ? buf[cur] : idn, fuse_ds ? cdp->w : nullptr,
-                                          fuse_ds ? cdp->bias : nullptr, buf[fr[3]], nx->w, nx->cout, nx->bias, buf[fr[0]], s, et);
+                                          fuse_ds ? cdp->bias : nullptr, outb, nx->w, nx->cout, nx->bias, buf[fr[0]], s, et);
                 prof_end(h, s, rt);
                 if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_tail launch (" + c3.conv_key + "): " + hipGetErrorString(e));
                 h3 = h2; w3 = w2;
                 pre_t1 = fr[0];
             } else if (cat_ds) {
-                rc = run_conv_cat(h, si, c3, *cdp, buf[fr[1]], buf[cur], n, h2, w2, hh, ww, buf[fr[3]], s);
+                rc = run_conv_cat(h, si, c3, *cdp, buf[fr[1]], buf[cur], n, h2, w2, hh, ww, outb, s);
                 if (rc) return rc;
                 h3 = h2; w3 = w2;
             } else {
@@ -1166,11 +1195,12 @@ after_pool:
                 // this conv's epilogue -- the 16-bit tensor is neither written nor read back (unless a tap asks for it)
                 const bool handover = (h->precision == R50_PREC_FP8 && h->fuse_fp8_handover && si == 0 && b == blocks - 1 && !tap &&
                                        (int)h->fp8_scales.size() == R50_FP8_NUM_SCALES);
-                rc = run_conv(h, c3, buf[fr[1]], n, h2, w2, idn, buf[fr[3]], 1, s, &h3, &w3, handover ? 1.0f / h->fp8_scales[0] : 0.f,
+                rc = run_conv(h, c3, buf[fr[1]], n, h2, w2, idn, outb, 1, s, &h3, &w3, handover ? 1.0f / h->fp8_scales[0] : 0.f,
                               handover ? &layer1_out_fp8 : nullptr);
                 if (rc) return rc;
             }
-            cur = fr[3]; hh = h3; ww = w3;
+            if (!inplace) cur = fr[3];
+            hh = h3; ww = w3;
             if (hit(p, buf[cur], hh, ww, c3.cout)) return R50_OK;
             li += (b == 0) ? 4 : 3;
         }
@@ -1537,6 +1567,9 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     }
     else if (k == "overlap_ds") h->overlap_ds = value ? 1 : 0;
     else if (k == "streams") { if (value < 1 || value > 4) return fail(h, R50_ERR_INVALID, "streams must be in [1,4]"); h->n_streams = (int)value; }
+    else if (k == "inplace_out") h->inplace_out = value ? 1 : 0;
+    else if (k == "xres_variant") g_xres_variant = (int)value;        // process-wide A/B knob
+    else if (k == "cu_cap") { if (value < 0 || value > 4096) return fail(h, R50_ERR_INVALID, "cu_cap must be in [0,4096]"); g_cu_cap = (int)value; g_num_cus = 0; }
     else return fail(h, R50_ERR_INVALID, "r50_set_option: unknown key " + k);
     return R50_OK;
 }
@@ -1548,6 +1581,8 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "profile") *value = h->profile;
     else if (k == "tile") *value = h->tile_override;
     else if (k == "streams") *value = h->n_streams;
+    else if (k == "cu_cap") *value = g_cu_cap;
+    else if (k == "inplace_out") *value = h->inplace_out;
     else if (k == "fused_stem") *value = h->fused_stem;
     else if (k == "fuse_tail") *value = h->fuse_tail;
     else if (k == "fuse_tail3") *value = h->fuse_tail3;

@@ -102,7 +102,11 @@ int r50_forward_layer(r50_handle* h, const float* x_nchw_f32_dev, int n, const c
  * "fuse_tail3" (layer3.1-.4: the same pair chained through LDS in one launch; default 1; needs "fuse_tail"),
  * "fuse_fp8_handover" (R50_PREC_FP8: layer1's output quantised to e4m3 in layer1.2.conv3's epilogue instead of in a pass of its
  * own; default 1; same bits either way),
- * "tile" (force an igemm tile id for every conv, 0 = tuned table; also turns "fuse_tail" off). */
+ * "tile" (force an igemm tile id for every conv, 0 = tuned table; also turns "fuse_tail" off),
+ * measurement knobs, all results bit-identical: "inplace_out" (1 = plain-identity blocks write their output over their input;
+ * default 0), and two PROCESS-WIDE ones: "cu_cap" (workgroups a persistent launch may use, 0 = every CU; for pipelines that share
+ * the chip) and "xres_variant" (schedule of the input-resident 3x3 kernel: 0 = default, 5 = mid-step barrier, 6 = + deeper weight
+ * ring, 7 = deeper ring only). */
 int r50_set_option(r50_handle* h, const char* key, int64_t value);
 int r50_get_option(r50_handle* h, const char* key, int64_t* value);
 

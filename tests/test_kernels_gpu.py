@@ -111,6 +111,39 @@ def test_conv2d_matches_oracle(lib_built, case):
         assert bool((buf[numel:] == -7.0).all()), f"conv tile={tile}: wrote past the end of the output"
 
 
+@pytest.mark.parametrize("shape", [(5, 7, 512), (3, 28, 128), (3, 14, 256), (70, 14, 256), (300, 14, 256), (260, 7, 512)],
+                         ids=lambda v: "n%d_%dx%d_c%d" % (v[0], v[1], v[1], v[2]))
+def test_xres_schedule_variants_bit_identical(lib_built, shape):
+    """conv3x3_xres_kernel: the mid-step-barrier schedule (next step's operands prefetched behind the barrier) and the deeper weight
+    rings are re-schedulings of the same MFMA sequence per accumulator -- the same bits as the default schedule, also with several
+    tiles per workgroup (n = 300 at 14x14: 600 tiles on 256 CUs) and with panels / cout tiles left ragged."""
+    from implementation_phd_lab_vision_amd import ops
+    from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
+    n, hw, c = shape
+    g = torch.Generator().manual_seed(n * 1000 + hw)
+    d = _dev()
+    x = _rand_bf16((n, hw, hw, c), g).to(d)
+    wt = _rand_bf16((c, 3, 3, c), g, scale=(2.0 / (9 * c)) ** 0.5).to(d)
+    bias = (torch.randn(c, generator=g) * 0.1).to(d)
+    bb = ResNet50Backbone(seed=0, max_batch=2).to(d)       # only to reach the process-wide option
+    try:
+        ref = None
+        for var in (0, 5, 6, 7, 0):
+            bb.set_option("xres_variant", var)
+            numel = n * hw * hw * c
+            buf = torch.full((numel + 512 * c,), -7.0, dtype=torch.bfloat16, device=d)
+            y = ops.conv2d_bf16(x, wt, bias, stride=1, pad=1, relu=True, tile=ops.TILE_XRES, out=buf)
+            torch.cuda.synchronize()
+            assert bool((buf[numel:] == -7.0).all()), f"variant {var}: wrote past the end of the output"
+            if ref is None:
+                ref = y.clone()
+            else:
+                assert torch.equal(y, ref), f"xres variant {var} differs from the default schedule"
+    finally:
+        bb.set_option("xres_variant", 0)
+        bb.close()
+
+
 @pytest.mark.parametrize("ds", [False, True], ids=["identity", "downsample"])
 @pytest.mark.parametrize("shape,c1", [((2, 7, 9), 64), ((1, 56, 56), 128), ((3, 5, 16), 64), ((5, 56, 56), 64)],
                          ids=lambda v: str(v).replace(" ", ""))
