@@ -2173,6 +2173,393 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Bottleneck BODY (layer2.1-.3), one launch per block: conv2 3x3 (128 -> 128) + bn2 + ReLU, conv3 1x1 (128 -> 512) + bn3 + identity +
+// ReLU and -- C1N = 128 -- the NEXT block's conv1 1x1 (512 -> 128) + bn1 + ReLU (src/preprocess_resnet_features.py:296 -> torchvision
+// Bottleneck.forward, restated in oracle/resnet50_oracle.py).
+// Why: at 28x28 the layer-wise form moves t1 in, t2 out (conv2 launch) and t2 in, identity in, block output out, next t1 out (fused
+// tail): 0.61 GB per block at batch 256.  Here t2 never leaves the CU (0.51 GB: 17 % fewer HBM bytes -- the first-order bound of
+// this network at batch 256 is its 10 GB of HBM traffic per step, not its 2.1 TFLOP) and the block is one launch instead of two.
+// All three GEMMs are 128 wide in their small dimension, so every accumulator set is 128 x 208 fp32 = 56 registers per consumer wave
+// and at most two are live (conv3 chunk + next conv1): the chained form fits the 168-register budget of 12 waves, unlike layer3's.
+// Tile = a band of 7 rows x 28 columns of one image = 196 pixels = 13 MFMA column blocks (1024 tiles at batch 256: four per CU).
+// 8 consumer waves (cout group w & 3: 32 rows of every 128-row weight stage; pixel half w >> 2: blocks 0..6 / 7..12) + 4 loader waves.
+// One STREAM of 16-KB weight stages [128 rows][64 K] runs through a ring of three LDS stages, one barrier per stage:
+//     conv2:  18 stages (chunk, tap) of W2 against the tile's t1 band -- both 64-channel chunks of the band, with halo, are resident
+//             in LDS (XB0, XB1), K order (chunk, tap, channel) exactly as conv3x3_xres_kernel: t2 has that kernel's bits
+//     then t2 = relu(acc) -> 16 bit -> LDS (T2: the B operand of conv3, two 64-channel K-slots of 208 pixel rows)
+//     for c in 0..3 (128 block-output channels each):
+//         A(c): 2 stages of W3[128c ..] against T2;   E(c): + identity, ReLU, 16 bit -> block output (HBM) and -> LDS (OUTC)
+//         B(c): 2 stages of W1[:, 128c ..] against OUTC into the next conv1's accumulators, which stay in registers over the chunks
+//     next t1 = relu(accB) -> HBM
+// Summation orders are those of the launches this replaces (bias first, K ascending, identity last with the same fp32 additions):
+// block output and next t1 are bit-identical to conv3x3_xres + igemm launches.
+// LDS: XB0 | XB1 (2 x 36,864: 270 padded positions x 128 B, chunk c of position q at c ^ (q & 7)); T2 (2 x 26,624) overlays them once
+// conv2 is done; OUTC (2 x 26,624) follows T2 and overlaps the end of XB1; ring 3 x 16,384; biases 3,072  = 158,720 B.
+// (C1N = 0, the stage's last block: no OUTC, and T2 sits behind XB0 so the next tile's first chunk can be fetched early.)
+// ------------------------------------------------------------------------------------------------
+struct Block2Args {
+    const __bf16* t1;     // (N,28,28,128)  this block's conv1 output
+    const __bf16* w2;     // (128, 3, 3, 128) folded conv2 weights, K-major (tap, cin)
+    const float* b2;      // (128)
+    const __bf16* w3;     // (512, 128)
+    const float* b3;      // (512)
+    const __bf16* res;    // (M, 512)  identity
+    __bf16* out;          // (M, 512)  block output
+    const __bf16* w1;     // (128, 512) next block's conv1 (C1N = 128)
+    const float* b1;      // (128)
+    __bf16* y1n;          // (M, 128)
+    int N;
+    int n_tiles;          // 4 N
+};
+
+template <int ET, int C1N>
+__global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(C1N == 0 || C1N == 128, "next conv1: none or 512 -> 128");
+    constexpr int IW = 28, TR = 7, PW = IW + 2, PP = (TR + 2) * PW;       // 270 padded positions
+    constexpr int XPASS = (PP + 31) / 32, XBUF = XPASS * 32 * 128;        // 9 passes, 36,864 B per 64-channel chunk
+    constexpr int NPX = TR * IW;                                          // 196
+    constexpr int SLOT = 208 * 128;                                       // one 64-channel K-slot of 208 pixel rows
+    // LDS map   C1N = 128:  XB0 | XB1 (T2 overlays them) | OUTC (one K-slot) | ring | biases        = 152,576 B
+    //           C1N = 0:    XB0 | XB1 ... T2 at 53,248 (over the end of XB1) ... | ring | biases     = 158,720 B
+    constexpr int XB_OFF = 0, T2_OFF = C1N ? 0 : 2 * SLOT, OUTC_OFF = 2 * XBUF, RING_OFF = C1N ? OUTC_OFF + SLOT : 4 * SLOT;
+    constexpr int NST = 3, WSTAGE = 128 * 128, WPASS = 4;
+    constexpr int BIAS_OFF = RING_OFF + NST * WSTAGE;                     // b2 (128) | b3 (512) | b1 (128) floats
+    // stages per tile: 18 of conv2, then  C1N = 0: 4 chunks of 128 couts x 2 K-slots of W3
+    //                                     C1N = 128: 8 chunks of 64 couts x { A: W3 rows, both K-slots in one stage ; B: W1 K-slice }
+    constexpr int NCONV = 18, SPT = NCONV + (C1N ? 16 : 8);
+    static_assert(T2_OFF + 2 * SLOT <= (C1N ? OUTC_OFF : RING_OFF) && 2 * XBUF <= (C1N ? OUTC_OFF : RING_OFF) && BIAS_OFF + 768 * 4 <= 163840, "LDS map");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grid = gridDim.x, first = blockIdx.x;
+
+    {
+        float v;
+        if (tid < 128) v = a.b2[tid];
+        else if (tid < 640) v = a.b3[tid - 128];
+        else v = (C1N ? a.b1[tid - 640] : 0.f);
+        reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = v;
+    }
+
+    if (wave >= 8) {
+        // =============================== loader waves ===============================================
+        const int lw = wave - 8, lt = tid - 512;
+        const int srow = lt >> 3, slot = lt & 7;
+        const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w2), 0, 128u * 1152u * 2u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w3), 0, 512u * 128u * 2u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w1), 0, C1N ? 128u * 512u * 2u : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.t1), 0, (unsigned)a.N * (784u * 256u), 0x00020000);
+        unsigned w2v[WPASS], w3v[WPASS], w1v[WPASS], x_voff[XPASS];
+#pragma unroll
+        for (int i = 0; i < WPASS; ++i) {
+            const int rho = i * 32 + srow;                               // LDS row of the stage
+            const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+            const unsigned ch = (unsigned)((slot ^ (rho & 7)) * 8);
+            w2v[i] = ((unsigned)cl * 1152u + ch) * 2u;
+            w1v[i] = ((unsigned)cl * 512u + ch) * 2u;
+            if (C1N) {                                                   // A stage: rows 64 ks + rho' = K-slot ks of cout perm(rho') of the chunk
+                const int rp = rho & 63, ks = rho >> 6;
+                const int cl2 = (rp & ~31) | (rp & 3) | (((rp >> 4) & 1) << 2) | (((rp >> 2) & 3) << 3);
+                w3v[i] = ((unsigned)cl2 * 128u + (unsigned)ks * 64u + ch) * 2u;
+            } else {
+                w3v[i] = ((unsigned)cl * 128u + ch) * 2u;
+            }
+        }
+        auto decode_band = [&](int tile) {        // source offsets of the padded positions of `tile` (out of range = zero border)
+            const int n = tile >> 2, band = tile & 3;
+#pragma unroll
+            for (int i = 0; i < XPASS; ++i) {
+                const int q = i * 32 + srow;
+                const int rr = q / PW, cc = q - rr * PW;
+                const int y = band * TR + rr - 1, x = cc - 1;
+                const bool ok = q < PP && tile < a.n_tiles && (unsigned)y < 28u && (unsigned)x < 28u;
+                x_voff[i] = ok ? (unsigned)(((n * 28 + y) * 28 + x) * 128 + (slot ^ (q & 7)) * 8) * 2u : kOobOffset;
+            }
+        };
+        auto issue_band = [&](int c2) {           // 9 DMAs per wave: chunk c2 of the band decoded last
+            const int xofs = __builtin_amdgcn_readfirstlane(c2 * 128);
+#pragma unroll
+            for (int i = 0; i < XPASS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + XB_OFF + c2 * XBUF + i * 4096 + lw * 1024), 16, x_voff[i], xofs, 0, 0);
+        };
+        int ring = 0;                             // ring slot of the next stage to issue
+        auto stage_issue = [&](int p) {           // stage p (0 .. SPT-1) of a tile; 4 DMAs per wave
+            char* sbase = smem + RING_OFF + ring * WSTAGE + lw * 1024;
+            ring = (ring == NST - 1) ? 0 : ring + 1;
+            if (p < NCONV) {
+                const int c2 = p >= 9 ? 1 : 0, tap = p - 9 * c2;
+                const int sofs = __builtin_amdgcn_readfirstlane((tap * 128 + c2 * 64) * 2);
+#pragma unroll
+                for (int i = 0; i < WPASS; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (LDS_AS void*)(sbase + i * 4096), 16, w2v[i], sofs, 0, 0);
+            } else {
+                const int q = p - NCONV, c = q >> 1, r = q & 1;
+                if (!C1N || r == 0) {
+                    const int sofs = __builtin_amdgcn_readfirstlane(C1N ? c * 64 * 128 * 2 : (c * 128 * 128 + r * 64) * 2);
+#pragma unroll
+                    for (int i = 0; i < WPASS; ++i)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (LDS_AS void*)(sbase + i * 4096), 16, w3v[i], sofs, 0, 0);
+                } else {
+                    const int sofs = __builtin_amdgcn_readfirstlane(c * 64 * 2);
+#pragma unroll
+                    for (int i = 0; i < WPASS; ++i)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (LDS_AS void*)(sbase + i * 4096), 16, w1v[i], sofs, 0, 0);
+                }
+            }
+        };
+        // all but the n youngest vector-memory operations of this wave are complete (n in {0, 4, 9, 13})
+        auto wait_younger = [&](int n) {
+            if (n == 13) { asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }
+            else if (n == 9) { asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
+            else if (n == 4) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        };
+        decode_band(first);
+        issue_band(0);
+        issue_band(1);
+        stage_issue(0);
+        stage_issue(1);
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");       // both band chunks and stage 0 landed (stage 1 may be in flight); bias writes done
+        __builtin_amdgcn_s_barrier();
+        bool first_tile = true;
+        // chunk 0 of the NEXT tile's band goes in once its LDS region is dead: C1N = 128: T2 overlays it, read until the last A stage
+        // (position SPT - 2), so it is issued at SPT - 1 and must land before that iteration's barrier (the next tile starts behind it);
+        // C1N = 0: T2 lies elsewhere, issued at SPT - 2 and waited for one iteration later with the stage issued behind it
+        constexpr int PBAND = C1N ? SPT - 1 : SPT - 2;
+#pragma unroll 1
+        for (int tile = first; tile < a.n_tiles; tile += grid) {
+            const bool has_next = tile + grid < a.n_tiles;
+#pragma unroll 1
+            for (int p = 0; p < SPT; ++p) {
+                // the consumers' extra barriers: T2 complete (in front of stage 18), OUTC(c) complete (in front of every B stage)
+                if (p == NCONV || (C1N && p > NCONV && ((p - NCONV) & 1) == 1)) __builtin_amdgcn_s_barrier();
+                int band_ops = 0;
+                // chunk 1 of THIS tile's band: its LDS region overlaps the previous tile's T2, free since that tile's last barrier
+                if (p == 0 && !first_tile) { issue_band(1); band_ops = XPASS; }
+                if (p == PBAND && has_next) { decode_band(tile + grid); issue_band(0); band_ops = (C1N ? 0 : XPASS); }
+                const bool st = (p + 2 < SPT) || has_next;
+                if (st) stage_issue(p + 2 < SPT ? p + 2 : p + 2 - SPT);
+                wait_younger((st ? WPASS : 0) + band_ops);          // stage p + 1 (and everything older) landed
+                __builtin_amdgcn_s_barrier();
+            }
+            first_tile = false;
+        }
+    } else {
+        // =============================== consumer waves =============================================
+        const int wave_c = wave & 3, wave_p = wave >> 2;                 // conv2 / next conv1: cout group (32 of 128), pixel half (blocks 0..6 / 7..12)
+        const int wave_a = wave & 1, wave_q = wave >> 1;                 // conv3 chunk (C1N = 128): cout group (32 of 64), pixel quarter (4 + 3 + 3 + 3 blocks)
+        const int qb0 = wave_q == 0 ? 0 : 1 + 3 * wave_q;
+        const int fr = lane & 15, fq = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.N * (784u * 1024u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.N * (784u * 1024u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.N * (784u * 256u), 0x00020000);
+        const int w_row = (wave_c * 32 + fr) * 128;                       // + m * 2048
+        const int w_rowa = (wave_a * 32 + fr) * 128;                      // A stage of the chained form: + ks * 8192 + m * 2048
+        const int w_ph0 = (fq ^ (fr & 7)) << 4;                          // kk = 0; kk = 1 is ^ 64
+        const int ch_lane = wave_c * 32 + 8 * fq;                        // this lane's 8 consecutive channels of a 128-channel group
+        const int cha_lane = wave_a * 32 + 8 * fq;                       // ... of a 64-channel chunk
+        // pixel row p = p0 + 16 j of block j: B fragment (kk = 0) at pb0 + 2048 j of a K-slot (p & 7 does not depend on j); kk = 1 is ^ 64
+        const int p0 = 16 * 7 * wave_p + fr, pb0 = p0 * 128 + ((fq ^ (p0 & 7)) << 4);
+        const int pa0 = 16 * qb0 + fr, pba0 = pa0 * 128 + ((fq ^ (pa0 & 7)) << 4);
+        // this lane's 8 channels of pixel row p as the B operand of the NEXT GEMM: chunk 4 (group & 1) + fq of K-slot group >> 1
+        const int cf_x = (wave_c & 1) << 6, cf_a = (wave_c >> 1) * SLOT;
+
+        auto run = [&](auto nrw_c, auto nq_c) {
+            constexpr int NRW = decltype(nrw_c)::value, NQ = decltype(nq_c)::value;
+            f32x4 acc[2][NRW], accA[2][NQ];
+            int cbuf = 0;
+            // acc[m][j] += W[rows 16 m + fr of `wb`][64 K] . X[64 K][pixel block j]; `xaddr(t)` = address of the fragment of slot t = NB kk + j
+            auto gemm64 = [&](auto nb_c, const char* wb, auto xaddr, auto& ac) {
+                constexpr int NB = decltype(nb_c)::value, NS = 2 * NB, PD = 3;
+                bf16x8 x[NS], wf[2], wg[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(wb + m * 2048 + w_ph0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) wg[m] = *reinterpret_cast<const bf16x8*>(wb + m * 2048 + (w_ph0 ^ 64));
+#pragma unroll
+                for (int t = 0; t < PD; ++t) x[t] = *reinterpret_cast<const bf16x8*>(xaddr(t));
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) ac[m][t % NB] = mfma_e<ET>(t >= NB ? wg[m] : wf[m], x[t], ac[m][t % NB]);
+                    if (t + PD < NS) x[t + PD] = *reinterpret_cast<const bf16x8*>(xaddr(t + PD));
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 + PD, 0);
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    if (t + PD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto stage_done = [&]() {             // the barrier stays behind the stage's last fragment read
+                cbuf = (cbuf == NST - 1) ? 0 : cbuf + 1;
+                __builtin_amdgcn_s_barrier();
+            };
+            auto pack_relu = [&](const f32x4& lo, const f32x4& hi) {
+                u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                return o;
+            };
+            auto add_identity = [&](f32x4& lo, f32x4& hi, const u32x4& r) {
+                lo[0] += unpack_lo_e<ET>(r[0]); lo[1] += unpack_hi_e<ET>(r[0]);
+                lo[2] += unpack_lo_e<ET>(r[1]); lo[3] += unpack_hi_e<ET>(r[1]);
+                hi[0] += unpack_lo_e<ET>(r[2]); hi[1] += unpack_hi_e<ET>(r[2]);
+                hi[2] += unpack_lo_e<ET>(r[3]); hi[3] += unpack_hi_e<ET>(r[3]);
+            };
+            constexpr std::integral_constant<int, NRW> NRWc{};
+            constexpr std::integral_constant<int, NQ> NQc{};
+#pragma unroll 1
+            for (int tile = first; tile < a.n_tiles; tile += grid) {
+                const unsigned tile_pix0 = (unsigned)((tile >> 2) * 784 + (tile & 3) * NPX);
+                // ---- conv2: bias, then 18 stages against the resident band
+                {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (ch_lane) * 4);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (ch_lane + 4) * 4);
+#pragma unroll
+                    for (int j = 0; j < NRW; ++j) { acc[0][j] = lo; acc[1][j] = hi; }
+                }
+                {
+                    // padded position of this lane's pixel of block j at tap (0,0); recomputed per tile (an opaque zero keeps the seven
+                    // values out of the registers that live across the whole tile loop: the chained tail needs them)
+                    int opq = 0;
+                    asm volatile("" : "+v"(opq));
+                    int q0[NRW];
+#pragma unroll
+                    for (int j = 0; j < NRW; ++j) {
+                        const int p = p0 + 16 * j + opq;
+                        const int pc = p < NPX ? p : NPX - 1;
+                        const int r = pc / IW, c = pc - r * IW;
+                        q0[j] = r * PW + c;
+                    }
+#pragma unroll 1
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        const char* xb = smem + XB_OFF + c2 * XBUF;
+#pragma unroll 1
+                        for (int tap = 0; tap < 9; ++tap) {
+                            const int kh = (tap >= 6) ? 2 : (tap >= 3) ? 1 : 0, kw = tap - 3 * kh;
+                            const int toff = kh * PW + kw;
+                            gemm64(NRWc, smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) {
+                                const int row = q0[t % NRW] + toff;
+                                return xb + row * 128 + ((((t >= NRW ? 4 : 0) + fq) ^ (row & 7)) << 4);
+                            }, acc);
+                            stage_done();
+                        }
+                    }
+                }
+                // ---- t2 = relu(acc) -> T2 (everybody is past the last conv2 stage's barrier: the band is dead)
+#pragma unroll
+                for (int j = 0; j < NRW; ++j)
+                    *reinterpret_cast<u32x4*>(smem + T2_OFF + cf_a + ((pb0 + 2048 * j) ^ cf_x)) = pack_relu(acc[0][j], acc[1][j]);
+                if constexpr (C1N != 0) {         // the next conv1's accumulators take over conv2's registers
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (640 + ch_lane) * 4);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (640 + ch_lane + 4) * 4);
+#pragma unroll
+                    for (int j = 0; j < NRW; ++j) { acc[0][j] = lo; acc[1][j] = hi; }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                   // T2 complete
+                if constexpr (C1N == 0) {
+                    const unsigned pix0 = tile_pix0 + (unsigned)p0;       // + 16 j
+#pragma unroll 1
+                    for (int c = 0; c < 4; ++c) {
+                        // identity slice of this chunk: requested now, used behind the two A stages
+                        u32x4 r[NRW];
+#pragma unroll
+                        for (int j = 0; j < NRW; ++j) {
+                            const unsigned voff = (p0 + 16 * j < NPX) ? ((pix0 + 16 * j) * 512u + (unsigned)(c * 128 + ch_lane)) * 2u : kOobOffset;
+                            r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff, 0, 0);
+                        }
+                        {
+                            const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (128 + c * 128 + ch_lane) * 4);
+                            const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (128 + c * 128 + ch_lane + 4) * 4);
+#pragma unroll
+                            for (int j = 0; j < NRW; ++j) { acc[0][j] = lo; acc[1][j] = hi; }
+                        }
+#pragma unroll 1
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const char* bb = smem + T2_OFF + ks * SLOT;
+                            gemm64(NRWc, smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) { return bb + ((pb0 + 2048 * (t % NRW)) ^ (t >= NRW ? 64 : 0)); }, acc);
+                            stage_done();
+                        }
+#pragma unroll
+                        for (int j = 0; j < NRW; ++j) {
+                            f32x4 lo = acc[0][j], hi = acc[1][j];
+                            add_identity(lo, hi, r[j]);
+                            const u32x4 o = pack_relu(lo, hi);
+                            const unsigned voff = (p0 + 16 * j < NPX) ? ((pix0 + 16 * j) * 512u + (unsigned)(c * 128 + ch_lane)) * 2u : kOobOffset;
+                            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, voff, 0, 0);
+                        }
+                    }
+                } else {
+                    const unsigned pixa = tile_pix0 + (unsigned)pa0;      // + 16 j
+#pragma unroll 1
+                    for (int c = 0; c < 8; ++c) {
+                        u32x4 r[NQ];
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j) {
+                            const unsigned voff = (pa0 + 16 * j < NPX) ? ((pixa + 16 * j) * 512u + (unsigned)(c * 64 + cha_lane)) * 2u : kOobOffset;
+                            r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff, 0, 0);
+                        }
+                        {
+                            const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (128 + c * 64 + cha_lane) * 4);
+                            const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (128 + c * 64 + cha_lane + 4) * 4);
+#pragma unroll
+                            for (int j = 0; j < NQ; ++j) { accA[0][j] = lo; accA[1][j] = hi; }
+                        }
+                        // ---- A(c): W3[64 c ..] . t2, both K-slots from ONE stage (rows 64 ks + ..)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const char* bb = smem + T2_OFF + ks * SLOT;
+                            gemm64(NQc, smem + RING_OFF + cbuf * WSTAGE + ks * 8192 + w_rowa, [&](int t) { return bb + ((pba0 + 2048 * (t % NQ)) ^ (t >= NQ ? 64 : 0)); }, accA);
+                        }
+                        stage_done();
+                        // ---- E(c): + identity, ReLU, 16 bit -> block output, and -> OUTC = the next conv1's K-slice
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j) {
+                            f32x4 lo = accA[0][j], hi = accA[1][j];
+                            add_identity(lo, hi, r[j]);
+                            const u32x4 o = pack_relu(lo, hi);
+                            const unsigned voff = (pa0 + 16 * j < NPX) ? ((pixa + 16 * j) * 512u + (unsigned)(c * 64 + cha_lane)) * 2u : kOobOffset;
+                            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, voff, 0, 0);
+                            *reinterpret_cast<u32x4*>(smem + OUTC_OFF + ((pba0 + 2048 * j) ^ (wave_a << 6))) = o;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();           // OUTC(c) complete
+                        // ---- B(c): W1[:, 64 c ..] . out_c into the next conv1's accumulators
+                        {
+                            const char* bb = smem + OUTC_OFF;
+                            gemm64(NRWc, smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) { return bb + ((pb0 + 2048 * (t % NRW)) ^ (t >= NRW ? 64 : 0)); }, acc);
+                            stage_done();
+                        }
+                    }
+                    const unsigned pix0 = tile_pix0 + (unsigned)p0;
+#pragma unroll
+                    for (int j = 0; j < NRW; ++j) {
+                        const u32x4 o = pack_relu(acc[0][j], acc[1][j]);
+                        const unsigned voff = (p0 + 16 * j < NPX) ? ((pix0 + 16 * j) * 128u + (unsigned)ch_lane) * 2u : kOobOffset;
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, voff, 0, 0);
+                    }
+                }
+            }
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's part of the biases is in LDS ...
+        __builtin_amdgcn_s_barrier();                           // ... and so is everybody's; band + stage 0 landed
+        if (wave_p == 0) {
+            if (wave_q == 0) run(std::integral_constant<int, 7>{}, std::integral_constant<int, 4>{});
+            else run(std::integral_constant<int, 7>{}, std::integral_constant<int, 3>{});
+        } else {
+            run(std::integral_constant<int, 6>{}, std::integral_constant<int, 3>{});
+        }
+    }
+#else
+    (void)a;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Frame producer: crop box + bilinear resize of decoded uint8 frames, on the device.
 // Reference: _crop_and_resize_video_uint8 (src/dataset.py:141-149) = slice [top:top+hh, left:left+ww] of the
 // (T,H,W,3) clip, then torchvision resize(..., [224,224], antialias=False) on uint8, which on an AVX2 CPU is ATen's

@@ -745,6 +745,31 @@ hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const
     return hipGetLastError();
 }
 
+// layer2.1-.3 bottleneck body in one launch (kernels.h: bneck_block2_kernel): conv2 + conv3 + identity + ReLU [+ the next block's conv1]
+hipError_t launch_bneck_block2(const void* t1, int n, const void* w2, const float* b2, const void* w3, const float* b3, const void* res,
+                               void* out, const void* w1, const float* b1, void* y1n, hipStream_t s, int et = 0) {
+    if (!t1 || !w2 || !b2 || !w3 || !b3 || !res || !out || n <= 0 || (long long)n * 784 * 1024 >= (1ll << 31)) return hipErrorInvalidValue;
+    if ((w1 == nullptr) != (b1 == nullptr) || (w1 == nullptr) != (y1n == nullptr)) return hipErrorInvalidValue;
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        g_num_cus = cu_budget(prop.multiProcessorCount);
+    }
+    Block2Args a;
+    a.t1 = (const __bf16*)t1; a.w2 = (const __bf16*)w2; a.b2 = b2; a.w3 = (const __bf16*)w3; a.b3 = b3; a.res = (const __bf16*)res;
+    a.out = (__bf16*)out; a.w1 = (const __bf16*)w1; a.b1 = b1; a.y1n = (__bf16*)y1n; a.N = n; a.n_tiles = 4 * n;
+    const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
+    const size_t lds = (w1 ? 2 * 36864 + 208 * 128 : 4 * 208 * 128) + 3 * 16384 + 768 * 4;       // 152,576 / 158,720 (kernels.h: LDS map)
+    void (*kern)(const Block2Args);
+    if (w1) kern = et == 1 ? bneck_block2_kernel<1, 128> : bneck_block2_kernel<0, 128>;
+    else kern = et == 1 ? bneck_block2_kernel<1, 0> : bneck_block2_kernel<0, 0>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, s, a);
+    return hipGetLastError();
+}
+
 // q_inv > 0: write the output as e4m3 = fp8(16-bit result * q_inv) (role-specialised tiles only; *q_done reports whether that happened)
 int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, int ww, const __bf16* res,
              __bf16* y, int relu, hipStream_t s, int* ho, int* wo, float q_inv = 0.f, bool* q_done = nullptr) {
@@ -1734,6 +1759,14 @@ int r50_op_bneck_tail(const void* y2, int64_t m, int cmid, const void* w3, const
     else e = hipErrorInvalidValue;
     if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
                                      std::string("r50_op_bneck_tail: ") + hipGetErrorString(e));
+    return R50_OK;
+}
+
+int r50_op_bneck_block2(const void* t1, int n, const void* w2, const float* b2, const void* w3, const float* b3, const void* res,
+                        void* out, const void* w1, const float* b1, void* y1n, void* stream) {
+    const hipError_t e = launch_bneck_block2(t1, n, w2, b2, w3, b3, res, out, w1, b1, y1n, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
+                                     std::string("r50_op_bneck_block2: ") + hipGetErrorString(e));
     return R50_OK;
 }
 

@@ -176,6 +176,35 @@ def bneck_tail_bf16(y2: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, identi
     return out, y1n
 
 
+def bneck_block2_bf16(t1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, identity: torch.Tensor,
+                      w1: Optional[torch.Tensor] = None, b1: Optional[torch.Tensor] = None):
+    """Layer2 bottleneck body in one launch (``r50_op_bneck_block2``): t1 (N,28,28,128), identity (N,28,28,512) bf16 NHWC; w2 (128,3,3,128),
+    w3 (512,128), w1 (128,512) bf16, K contiguous; biases fp32.  Returns (block output (N,28,28,512), next t1 (N,28,28,128) or None)."""
+    for t, name in ((t1, "t1"), (w2, "w2"), (w3, "w3"), (identity, "identity")):
+        _need(t, torch.bfloat16, name)
+    _need(b2, torch.float32, "b2"); _need(b3, torch.float32, "b3")
+    n = t1.shape[0]
+    if tuple(t1.shape) != (n, 28, 28, 128) or tuple(identity.shape) != (n, 28, 28, 512) or tuple(w2.shape) != (128, 3, 3, 128) \
+            or tuple(w3.shape) != (512, 128) or b2.numel() != 128 or b3.numel() != 512:
+        raise ValueError("bneck_block2_bf16: inconsistent shapes")
+    if (w1 is None) != (b1 is None):
+        raise ValueError("bneck_block2_bf16: w1 and b1 go together")
+    out = torch.empty((n, 28, 28, 512), dtype=torch.bfloat16, device=t1.device)
+    y1n = None
+    if w1 is not None:
+        _need(w1, torch.bfloat16, "w1"); _need(b1, torch.float32, "b1")
+        if tuple(w1.shape) != (128, 512) or b1.numel() != 128:
+            raise ValueError("bneck_block2_bf16: inconsistent next-conv1 shapes")
+        y1n = torch.empty((n, 28, 28, 128), dtype=torch.bfloat16, device=t1.device)
+    with torch.cuda.device(t1.device):
+        rc = _lib.load_library().r50_op_bneck_block2(t1.data_ptr(), n, w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(),
+                                                     identity.data_ptr(), out.data_ptr(),
+                                                     w1.data_ptr() if w1 is not None else None, b1.data_ptr() if b1 is not None else None,
+                                                     y1n.data_ptr() if y1n is not None else None, _stream(t1))
+    _lib.check(rc, None, "r50_op_bneck_block2")
+    return out, y1n
+
+
 def stem_bf16(x_nchw: torch.Tensor, w_folded_oihw: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """conv1 7x7 s2 p3 + folded bn1 + ReLU: (N,3,224,224) fp32 NCHW -> (N,112,112,64) bf16 NHWC.
     ``w_folded_oihw``: (64,3,7,7) fp32 on the HOST (already BN-folded); ``bias``: (64) fp32 on the GPU."""

@@ -195,6 +195,15 @@ int r50_op_bneck_tail(const void* y2_bf16, int64_t m, int cmid, const void* w3_b
                       const void* identity_bf16, const void* wd_bf16, const float* bd, void* out_bf16, const void* w1_bf16,
                       int c1, const float* b1, void* y1n_bf16, void* stream);
 
+/* A whole bottleneck BODY of layer2 (blocks .1-.3, 28x28, 128 mid channels) in one launch: t2 = relu(conv2_3x3(t1) + b2) stays in LDS,
+ * out = relu(w3 . t2 + b3 + identity) and, when w1 / b1 / y1n are given, y1n = relu(w1 . out + b1) (the next block's conv1) --
+ * `Bottleneck.forward` of torchvision's ResNet-50 from its second conv on (src/preprocess_resnet_features.py:296 calls it through
+ * nn.Sequential).  t1 (n,28,28,128), identity / out (n,28,28,512), y1n (n,28,28,128) bf16 NHWC; w2 (128,3,3,128), w3 (512,128),
+ * w1 (128,512) folded bf16, K contiguous; biases fp32.  Bit for bit what r50_op_conv2d (3x3, input-resident tile) followed by two
+ * r50_op_conv2d 1x1 launches give.  w1 = b1 = y1n = NULL: no next conv1 (the stage's last block). */
+int r50_op_bneck_block2(const void* t1_bf16, int n, const void* w2_bf16, const float* b2, const void* w3_bf16, const float* b3,
+                        const void* identity_bf16, void* out_bf16, const void* w1_bf16, const float* b1, void* y1n_bf16, void* stream);
+
 /* Frame producer, the step before the path: crop box + bilinear resize of a decoded clip on the
  * device.  Replaces `_crop_and_resize_video_uint8` (src/dataset.py:141-149) up to, not including, the `/255`:
  * frames (t,h,w,3) uint8 HWC as the video decoder returns them -> `frames[:, top:top+hh, left:left+ww]` ->

@@ -144,6 +144,34 @@ def test_xres_schedule_variants_bit_identical(lib_built, shape):
         bb.close()
 
 
+@pytest.mark.parametrize("chain", [False, True], ids=["last_block", "chained_conv1"])
+@pytest.mark.parametrize("n", [1, 3, 70])
+def test_bneck_block2_equals_unfused(lib_built, n, chain):
+    """Layer2 bottleneck body in one launch (conv2 3x3 + conv3 + identity + ReLU [+ next conv1]): block output and next t1 are the
+    same bits as the input-resident 3x3 launch followed by the 1x1 igemm launches (n = 70: 280 tiles, more than one per workgroup)."""
+    from implementation_phd_lab_vision_amd import ops
+    g = torch.Generator().manual_seed(4100 + n)
+    d = _dev()
+    t1 = _rand_bf16((n, 28, 28, 128), g).clamp_(min=0).to(d)
+    idn = _rand_bf16((n, 28, 28, 512), g).clamp_(min=0).to(d)
+    w2 = _rand_bf16((128, 3, 3, 128), g, scale=(2.0 / 1152) ** 0.5).to(d)
+    w3 = _rand_bf16((512, 1, 1, 128), g, scale=(2.0 / 128) ** 0.5).to(d)
+    w1 = _rand_bf16((128, 1, 1, 512), g, scale=(2.0 / 512) ** 0.5).to(d)
+    b2 = (torch.randn(128, generator=g) * 0.1).to(d)
+    b3 = (torch.randn(512, generator=g) * 0.1).to(d)
+    b1 = (torch.randn(128, generator=g) * 0.1).to(d)
+    t2 = ops.conv2d_bf16(t1, w2, b2, stride=1, pad=1, relu=True, tile=ops.TILE_XRES)
+    out_ref = ops.conv2d_bf16(t2, w3, b3, stride=1, pad=0, relu=True, residual=idn)
+    y1_ref = ops.conv2d_bf16(out_ref, w1, b1, stride=1, pad=0, relu=True)
+    out, y1n = ops.bneck_block2_bf16(t1, w2, b2, w3.view(512, 128), b3, idn, w1.view(128, 512) if chain else None, b1 if chain else None)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_ref), f"block output differs: max |diff| {float((out.float() - out_ref.float()).abs().max())}"
+    if chain:
+        assert torch.equal(y1n, y1_ref), f"next conv1 differs: max |diff| {float((y1n.float() - y1_ref.float()).abs().max())}"
+    else:
+        assert y1n is None
+
+
 @pytest.mark.parametrize("ds", [False, True], ids=["identity", "downsample"])
 @pytest.mark.parametrize("shape,c1", [((2, 7, 9), 64), ((1, 56, 56), 128), ((3, 5, 16), 64), ((5, 56, 56), 64)],
                          ids=lambda v: str(v).replace(" ", ""))
