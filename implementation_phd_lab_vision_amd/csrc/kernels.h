@@ -2220,15 +2220,16 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
     constexpr int XPASS = (PP + 31) / 32, XBUF = XPASS * 32 * 128;        // 9 passes, 36,864 B per 64-channel chunk
     constexpr int NPX = TR * IW;                                          // 196
     constexpr int SLOT = 208 * 128;                                       // one 64-channel K-slot of 208 pixel rows
-    // LDS map   C1N = 128:  XB0 | XB1 (T2 overlays them) | OUTC (one K-slot) | ring | biases        = 152,576 B
-    //           C1N = 0:    XB0 | XB1 ... T2 at 53,248 (over the end of XB1) ... | ring | biases     = 158,720 B
-    constexpr int XB_OFF = 0, T2_OFF = C1N ? 0 : 2 * SLOT, OUTC_OFF = 2 * XBUF, RING_OFF = C1N ? OUTC_OFF + SLOT : 4 * SLOT;
+    // LDS map   C1N = 128:  XB0 | XB1 (T2 at 0 and OUTC at 53,248, one K-slot, overlay them) | RESB (224 rows) | ring | biases = 160,768 B
+    //           C1N = 0:    XB0 | XB1 ... T2 at 53,248 (over the end of XB1) ... | ring | biases                              = 158,720 B
+    constexpr int XB_OFF = 0, T2_OFF = C1N ? 0 : 2 * SLOT, OUTC_OFF = 2 * SLOT, RESB_OFF = 3 * SLOT, RESB_BYTES = 224 * 128;
+    constexpr int RING_OFF = C1N ? RESB_OFF + RESB_BYTES : 4 * SLOT;
     constexpr int NST = 3, WSTAGE = 128 * 128, WPASS = 4;
     constexpr int BIAS_OFF = RING_OFF + NST * WSTAGE;                     // b2 (128) | b3 (512) | b1 (128) floats
     // stages per tile: 18 of conv2, then  C1N = 0: 4 chunks of 128 couts x 2 K-slots of W3
     //                                     C1N = 128: 8 chunks of 64 couts x { A: W3 rows, both K-slots in one stage ; B: W1 K-slice }
     constexpr int NCONV = 18, SPT = NCONV + (C1N ? 16 : 8);
-    static_assert(T2_OFF + 2 * SLOT <= (C1N ? OUTC_OFF : RING_OFF) && 2 * XBUF <= (C1N ? OUTC_OFF : RING_OFF) && BIAS_OFF + 768 * 4 <= 163840, "LDS map");
+    static_assert(2 * XBUF <= (C1N ? RESB_OFF : RING_OFF) && BIAS_OFF + 768 * 4 <= 163840, "LDS map");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2250,6 +2251,8 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
         const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w3), 0, 512u * 128u * 2u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w1), 0, C1N ? 128u * 512u * 2u : 0u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.t1), 0, (unsigned)a.N * (784u * 256u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.N * (784u * 1024u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.N * (784u * 1024u), 0x00020000);
         unsigned w2v[WPASS], w3v[WPASS], w1v[WPASS], x_voff[XPASS];
 #pragma unroll
         for (int i = 0; i < WPASS; ++i) {
@@ -2283,6 +2286,28 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
             for (int i = 0; i < XPASS; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + XB_OFF + c2 * XBUF + i * 4096 + lw * 1024), 16, x_voff[i], xofs, 0, 0);
         };
+        // C1N = 128: the identity and the block output move in FULL 128-B row pieces through the loaders (row R = 32 i + srow of the
+        // tile, 16-B chunk slot ^ (R & 7) of the 64-channel chunk): identity rows by LDS-DMA into RESB one chunk ahead, out_c copied
+        // from OUTC to HBM with 16-B stores -- the consumers' own accesses would be MFMA-fragment shaped (16 rows x 64 B per
+        // instruction), several times the address-unit cost per byte
+        auto row_voff = [&](int i, unsigned tile_pix0) -> unsigned {
+            const int R = 32 * i + srow;
+            return R < NPX ? ((tile_pix0 + (unsigned)R) * 512u + (unsigned)((slot ^ (R & 7)) * 8)) * 2u : kOobOffset;
+        };
+        auto issue_res = [&](unsigned tile_pix0, int c) {       // 7 DMAs per wave
+            const int cofs = __builtin_amdgcn_readfirstlane(c * 128);
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(smem + RESB_OFF + i * 4096 + lw * 1024), 16, row_voff(i, tile_pix0), cofs, 0, 0);
+        };
+        auto copy_out = [&](unsigned tile_pix0, int c) {        // 7 LDS reads + 7 stores per wave
+            const int cofs = __builtin_amdgcn_readfirstlane(c * 128);
+            u32x4 v[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) v[i] = *reinterpret_cast<const u32x4*>(smem + OUTC_OFF + i * 4096 + lt * 16);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, row_voff(i, tile_pix0), cofs, 0);
+        };
         int ring = 0;                             // ring slot of the next stage to issue
         auto stage_issue = [&](int p) {           // stage p (0 .. SPT-1) of a tile; 4 DMAs per wave
             char* sbase = smem + RING_OFF + ring * WSTAGE + lw * 1024;
@@ -2308,12 +2333,13 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
                 }
             }
         };
-        // all but the n youngest vector-memory operations of this wave are complete (n in {0, 4, 9, 13})
+        // all but the n youngest vector-memory operations of this wave are complete
         auto wait_younger = [&](int n) {
-            if (n == 13) { asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }
-            else if (n == 9) { asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
-            else if (n == 4) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-            else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            bool done = false;
+#pragma unroll
+            for (int e = 1; e <= 27; ++e)
+                if (!done && n == e) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(e) : "memory"); done = true; }
+            if (!done) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         };
         decode_band(first);
         issue_band(0);
@@ -2323,6 +2349,7 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");       // both band chunks and stage 0 landed (stage 1 may be in flight); bias writes done
         __builtin_amdgcn_s_barrier();
         bool first_tile = true;
+        int carry = 0;                            // stores of the previous iteration (issued behind its DMAs)
         // chunk 0 of the NEXT tile's band goes in once its LDS region is dead: C1N = 128: T2 overlays it, read until the last A stage
         // (position SPT - 2), so it is issued at SPT - 1 and must land before that iteration's barrier (the next tile starts behind it);
         // C1N = 0: T2 lies elsewhere, issued at SPT - 2 and waited for one iteration later with the stage issued behind it
@@ -2330,17 +2357,29 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
 #pragma unroll 1
         for (int tile = first; tile < a.n_tiles; tile += grid) {
             const bool has_next = tile + grid < a.n_tiles;
+            const unsigned tile_pix0 = (unsigned)((tile >> 2) * 784 + (tile & 3) * NPX);
 #pragma unroll 1
             for (int p = 0; p < SPT; ++p) {
                 // the consumers' extra barriers: T2 complete (in front of stage 18), OUTC(c) complete (in front of every B stage)
                 if (p == NCONV || (C1N && p > NCONV && ((p - NCONV) & 1) == 1)) __builtin_amdgcn_s_barrier();
-                int band_ops = 0;
-                // chunk 1 of THIS tile's band: its LDS region overlaps the previous tile's T2, free since that tile's last barrier
-                if (p == 0 && !first_tile) { issue_band(1); band_ops = XPASS; }
-                if (p == PBAND && has_next) { decode_band(tile + grid); issue_band(0); band_ops = (C1N ? 0 : XPASS); }
+                // `younger`: operations issued behind the last one that has to be complete at this iteration's barrier
+                int younger = carry;
+                carry = 0;
+                // chunk 1 of THIS tile's band: its LDS region overlaps the previous tile's T2 / OUTC, free since that tile's last barrier
+                if (p == 0 && !first_tile) { issue_band(1); younger += XPASS; }
+                if (p == PBAND && has_next) { decode_band(tile + grid); issue_band(0); if (C1N) younger = 0; else younger += XPASS; }
+                const bool bpos = C1N && p > NCONV && ((p - NCONV) & 1) == 1;      // B stage of chunk (p - 19) / 2
+                // identity rows of the NEXT chunk (chunk 0: two stages before the first A stage): needed one barrier later
+                if (C1N && p == NCONV - 2) { issue_res(tile_pix0, 0); younger += 7; }
+                if (bpos && p + 1 < SPT) { issue_res(tile_pix0, (p - NCONV + 1) / 2); younger += 7; }
                 const bool st = (p + 2 < SPT) || has_next;
-                if (st) stage_issue(p + 2 < SPT ? p + 2 : p + 2 - SPT);
-                wait_younger((st ? WPASS : 0) + band_ops);          // stage p + 1 (and everything older) landed
+                if (st) { stage_issue(p + 2 < SPT ? p + 2 : p + 2 - SPT); younger += WPASS; }
+                if (bpos) {                       // out_c is complete (the extra barrier above): LDS -> HBM; the stores are not waited for here
+                    copy_out(tile_pix0, (p - NCONV) / 2);
+                    younger += 7;
+                    carry = 7;                    // ... nor at the next iteration, whose wait covers this iteration's DMAs
+                }
+                wait_younger(younger);            // stage p + 1, the band chunk / identity rows due now and everything older landed
                 __builtin_amdgcn_s_barrier();
             }
             first_tile = false;
@@ -2494,15 +2533,8 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
                         }
                     }
                 } else {
-                    const unsigned pixa = tile_pix0 + (unsigned)pa0;      // + 16 j
 #pragma unroll 1
                     for (int c = 0; c < 8; ++c) {
-                        u32x4 r[NQ];
-#pragma unroll
-                        for (int j = 0; j < NQ; ++j) {
-                            const unsigned voff = (pa0 + 16 * j < NPX) ? ((pixa + 16 * j) * 512u + (unsigned)(c * 64 + cha_lane)) * 2u : kOobOffset;
-                            r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff, 0, 0);
-                        }
                         {
                             const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (128 + c * 64 + cha_lane) * 4);
                             const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (128 + c * 64 + cha_lane + 4) * 4);
@@ -2516,15 +2548,18 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
                             gemm64(NQc, smem + RING_OFF + cbuf * WSTAGE + ks * 8192 + w_rowa, [&](int t) { return bb + ((pba0 + 2048 * (t % NQ)) ^ (t >= NQ ? 64 : 0)); }, accA);
                         }
                         stage_done();
-                        // ---- E(c): + identity, ReLU, 16 bit -> block output, and -> OUTC = the next conv1's K-slice
+                        // ---- E(c): + identity (RESB, landed with this stage's barrier), ReLU, 16 bit -> OUTC: the block output's chunk (the
+                        //      loaders copy it out) and the next conv1's K-slice
+                        {
+                            u32x4 r[NQ];
 #pragma unroll
-                        for (int j = 0; j < NQ; ++j) {
-                            f32x4 lo = accA[0][j], hi = accA[1][j];
-                            add_identity(lo, hi, r[j]);
-                            const u32x4 o = pack_relu(lo, hi);
-                            const unsigned voff = (pa0 + 16 * j < NPX) ? ((pixa + 16 * j) * 512u + (unsigned)(c * 64 + cha_lane)) * 2u : kOobOffset;
-                            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, voff, 0, 0);
-                            *reinterpret_cast<u32x4*>(smem + OUTC_OFF + ((pba0 + 2048 * j) ^ (wave_a << 6))) = o;
+                            for (int j = 0; j < NQ; ++j) r[j] = *reinterpret_cast<const u32x4*>(smem + RESB_OFF + ((pba0 + 2048 * j) ^ (wave_a << 6)));
+#pragma unroll
+                            for (int j = 0; j < NQ; ++j) {
+                                f32x4 lo = accA[0][j], hi = accA[1][j];
+                                add_identity(lo, hi, r[j]);
+                                *reinterpret_cast<u32x4*>(smem + OUTC_OFF + ((pba0 + 2048 * j) ^ (wave_a << 6))) = pack_relu(lo, hi);
+                            }
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();           // OUTC(c) complete

@@ -760,7 +760,7 @@ hipError_t launch_bneck_block2(const void* t1, int n, const void* w2, const floa
     a.t1 = (const __bf16*)t1; a.w2 = (const __bf16*)w2; a.b2 = b2; a.w3 = (const __bf16*)w3; a.b3 = b3; a.res = (const __bf16*)res;
     a.out = (__bf16*)out; a.w1 = (const __bf16*)w1; a.b1 = b1; a.y1n = (__bf16*)y1n; a.N = n; a.n_tiles = 4 * n;
     const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
-    const size_t lds = (w1 ? 2 * 36864 + 208 * 128 : 4 * 208 * 128) + 3 * 16384 + 768 * 4;       // 152,576 / 158,720 (kernels.h: LDS map)
+    const size_t lds = (w1 ? 3 * 208 * 128 + 224 * 128 : 4 * 208 * 128) + 3 * 16384 + 768 * 4;       // 160,768 / 158,720 (kernels.h: LDS map)
     void (*kern)(const Block2Args);
     if (w1) kern = et == 1 ? bneck_block2_kernel<1, 128> : bneck_block2_kernel<0, 128>;
     else kern = et == 1 ? bneck_block2_kernel<1, 0> : bneck_block2_kernel<0, 0>;
