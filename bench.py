@@ -199,6 +199,7 @@ def main() -> None:
     ap.add_argument("--no-stem-c1", action="store_true", help="A/B: layer1.0.conv1 as its own igemm launch instead of inside the stem kernel")
     ap.add_argument("--no-ds-cat", action="store_true", help="A/B: downsample conv and conv3 of layer2.0 / 3.0 / 4.0 as separate launches")
     ap.add_argument("--no-overlap-ds", action="store_true", help="A/B: downsample convs on the main stream")
+    ap.add_argument("--no-block2", action="store_true", help="A/B: layer2.1-.3 as conv2 launch + fused tail instead of one launch per bottleneck body")
     ap.add_argument("--inplace", action="store_true", help="A/B: plain-identity blocks write their output over their input (same bits; measured: no gain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat", type=float, default=1.0,
@@ -259,6 +260,8 @@ def main() -> None:
         bb.set_option("overlap_ds", 0)
     if args.inplace:
         bb.set_option("inplace_out", 1)
+    if args.no_block2:
+        bb.set_option("fuse_block2", 0)
     x = synthetic_frames(args.batch, seed=1234 + rank).to(dev)          # random data, resident in HBM
     run = bb.features
     if args.input == "u8":
@@ -399,7 +402,13 @@ def main() -> None:
                                         "avg_launch_us": 1e3 * t3["ms"] / max(1, t3["launches"]),
                                         "tflops": t3["flops"] / (t3["ms"] * 1e-3) / 1e12, "frac_of_mfma_peak": t3["flops"] / (t3["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                         "GBps": t3["bytes"] / (t3["ms"] * 1e-3) / 1e9, "frac_of_hbm_peak": t3["bytes"] / (t3["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-        classes = ("igemm", "bneck_tail", "bneck_tail3", "conv1", "maxpool", "avgpool", "stem_pack")
+        b2 = prof.get("bneck_block2")
+        if b2 and b2["ms"] > 0:       # layer2.1-.3 bottleneck bodies in one launch each: MFMA work and HBM streaming at once
+            roofline["fourth_kernel"] = {"kernel": "bneck_block2_kernel (%d launches/step)" % round(b2["launches"] / max(1, args.steps)),
+                                         "avg_launch_us": 1e3 * b2["ms"] / max(1, b2["launches"]),
+                                         "tflops": b2["flops"] / (b2["ms"] * 1e-3) / 1e12, "frac_of_mfma_peak": b2["flops"] / (b2["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                         "GBps": b2["bytes"] / (b2["ms"] * 1e-3) / 1e9, "frac_of_hbm_peak": b2["bytes"] / (b2["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        classes = ("igemm", "bneck_tail", "bneck_tail3", "bneck_block2", "conv1", "maxpool", "avgpool", "stem_pack")
         tot_ms = sum(prof[k]["ms"] for k in classes if k in prof)
         kernels = {k: {"launches_per_step": prof[k]["launches"] / args.steps, "ms_per_step": prof[k]["ms"] / args.steps,
                        "share": prof[k]["ms"] / tot_ms if tot_ms else 0.0} for k in classes if k in prof and prof[k]["launches"]}

@@ -22,8 +22,8 @@ struct Prof {
     int64_t launches = 0;
     double ms = 0, flops = 0, bytes = 0;
 };
-enum ProfClass { PC_IGEMM = 0, PC_STEM_CONV, PC_MAXPOOL, PC_AVGPOOL, PC_STEM_PACK, PC_TAIL, PC_TAIL3, PC_COUNT };
-const char* kProfNames[PC_COUNT] = {"igemm", "conv1", "maxpool", "avgpool", "stem_pack", "bneck_tail", "bneck_tail3"};
+enum ProfClass { PC_IGEMM = 0, PC_STEM_CONV, PC_MAXPOOL, PC_AVGPOOL, PC_STEM_PACK, PC_TAIL, PC_TAIL3, PC_BLOCK2, PC_COUNT };
+const char* kProfNames[PC_COUNT] = {"igemm", "conv1", "maxpool", "avgpool", "stem_pack", "bneck_tail", "bneck_tail3", "bneck_block2"};
 
 struct EvRec {
     hipEvent_t a, b;
@@ -69,6 +69,7 @@ struct r50_handle {
     int fuse_fp8_handover = 1;          // fp8 mode: quantise layer1's output in layer1.2.conv3's epilogue instead of in a pass of its own
     int fuse_tail3 = 1;                 // layer3.1-.4: conv3 + identity + ReLU chained with the next block's conv1 through LDS (bneck_tail3_kernel)
     __bf16* tail3_wp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per layer3 block b: [W3(b) | W1(b+1)] in the kernel's fragment order
+    int fuse_block2 = 1;                // layer2.1-.3: the whole bottleneck body (conv2 + conv3 + identity + ReLU [+ next conv1]) in one launch
     int inplace_out = 0;                // plain-identity blocks write their output over their input (same bits, fewer DRAM page switches)
     int n_streams = 1;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1166,6 +1167,31 @@ after_pool:
                 HIP_TRY(h, hipEventRecord(h->ev_ds_join, sd));
                 idn = buf[fr[2]];
             }
+            // layer2.1-.3: the bottleneck body from conv2 on is ONE launch (kernels.h: bneck_block2_kernel) -- t2 never leaves the CU, and
+            // in .1 / .2 the next block's conv1 is chained through LDS as in the fused tails.  Same bits as the launches it replaces.
+            const bool block2 = h->fuse_block2 && h->fuse_tail && !split && !tap && si == 1 && b > 0 && h->tile_override == 0 && !ds_side &&
+                                (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16) && hh == 28 && ww == 28 && c1.cout == 128 &&
+                                c2.ks == 3 && c2.stride == 1 && c2.pad == 1 && c2.cin == 128 && c2.cout == 128 && c3.ks == 1 && c3.cin == 128 && c3.cout == 512;
+            if (block2) {
+                if (!have_t1) {
+                    rc = run_conv(h, c1, buf[cur], n, hh, ww, nullptr, buf[fr[0]], 1, s, &h1, &w1);
+                    if (rc) return rc;
+                }
+                const bool chain = nx && nx->ks == 1 && nx->stride == 1 && nx->cin == 512 && nx->cout == 128;
+                const double m = (double)n * 784.0;
+                EvRec rb{};
+                prof_begin(h, s, rb, PC_BLOCK2, 2.0 * m * (128.0 * 1152 + 512.0 * 128 + (chain ? 128.0 * 512 : 0.0)),
+                           2.0 * (m * (128.0 + 512 + 512 + (chain ? 128.0 : 0.0)) + 128.0 * 1152 + 512.0 * 128 + (chain ? 128.0 * 512 : 0.0)),
+                           (int)(&c2 - &h->convs[0]));
+                e = launch_bneck_block2(buf[fr[0]], n, c2.w, c2.bias, c3.w, c3.bias, buf[cur], buf[fr[3]], chain ? nx->w : nullptr,
+                                        chain ? nx->bias : nullptr, chain ? buf[fr[1]] : nullptr, s, et);
+                prof_end(h, s, rb);
+                if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_block2 launch (" + c2.conv_key + "): " + hipGetErrorString(e));
+                if (chain) pre_t1 = fr[1];
+                cur = fr[3];
+                li += 3;
+                continue;
+            }
             if (have_t1) {
                 h1 = hh; w1 = ww;
             } else {
@@ -1593,6 +1619,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "overlap_ds") h->overlap_ds = value ? 1 : 0;
     else if (k == "streams") { if (value < 1 || value > 4) return fail(h, R50_ERR_INVALID, "streams must be in [1,4]"); h->n_streams = (int)value; }
     else if (k == "inplace_out") h->inplace_out = value ? 1 : 0;
+    else if (k == "fuse_block2") h->fuse_block2 = value ? 1 : 0;
     else if (k == "xres_variant") g_xres_variant = (int)value;        // process-wide A/B knob
     else if (k == "cu_cap") { if (value < 0 || value > 4096) return fail(h, R50_ERR_INVALID, "cu_cap must be in [0,4096]"); g_cu_cap = (int)value; g_num_cus = 0; }
     else return fail(h, R50_ERR_INVALID, "r50_set_option: unknown key " + k);
@@ -1608,6 +1635,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "streams") *value = h->n_streams;
     else if (k == "cu_cap") *value = g_cu_cap;
     else if (k == "inplace_out") *value = h->inplace_out;
+    else if (k == "fuse_block2") *value = h->fuse_block2;
     else if (k == "fused_stem") *value = h->fused_stem;
     else if (k == "fuse_tail") *value = h->fuse_tail;
     else if (k == "fuse_tail3") *value = h->fuse_tail3;

@@ -100,6 +100,8 @@ int r50_forward_layer(r50_handle* h, const float* x_nchw_f32_dev, int n, const c
  * "overlap_ds" (1 = downsample convs on a side stream; default 0), "fused_stem" (default 1),
  * "fuse_tail" (layer1 / layer2: conv3 + identity + ReLU + the next block's conv1 in one kernel; default 1),
  * "fuse_tail3" (layer3.1-.4: the same pair chained through LDS in one launch; default 1; needs "fuse_tail"),
+ * "fuse_block2" (layer2.1-.3: conv2 + conv3 + identity + ReLU [+ the next conv1] in one launch, t2 kept in LDS; default 1; needs
+ * "fuse_tail"; same bits),
  * "fuse_fp8_handover" (R50_PREC_FP8: layer1's output quantised to e4m3 in layer1.2.conv3's epilogue instead of in a pass of its
  * own; default 1; same bits either way),
  * "tile" (force an igemm tile id for every conv, 0 = tuned table; also turns "fuse_tail" off),
