@@ -2212,6 +2212,11 @@ struct Block2Args {
     int n_tiles;          // 4 N
 };
 
+// Diagnostic ablations (scripts/build_variant.sh -DB2_ABL=mask; timing only, results are wrong): 1 = no MFMAs (reads stay live),
+// 2 = identity DMAs zero-fill and the block output is not stored, 4 = band DMAs zero-fill, 8 = weight-stage DMAs zero-fill
+#ifndef B2_ABL
+#define B2_ABL 0
+#endif
 template <int ET, int C1N>
 __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2261,6 +2266,7 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
             const unsigned ch = (unsigned)((slot ^ (rho & 7)) * 8);
             w2v[i] = ((unsigned)cl * 1152u + ch) * 2u;
             w1v[i] = ((unsigned)cl * 512u + ch) * 2u;
+            if (B2_ABL & 8) { w2v[i] = kOobOffset; w1v[i] = kOobOffset; }
             if (C1N) {                                                   // A stage: rows 64 ks + rho' = K-slot ks of cout perm(rho') of the chunk
                 const int rp = rho & 63, ks = rho >> 6;
                 const int cl2 = (rp & ~31) | (rp & 3) | (((rp >> 4) & 1) << 2) | (((rp >> 2) & 3) << 3);
@@ -2268,6 +2274,7 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
             } else {
                 w3v[i] = ((unsigned)cl * 128u + ch) * 2u;
             }
+            if (B2_ABL & 8) w3v[i] = kOobOffset;
         }
         auto decode_band = [&](int tile) {        // source offsets of the padded positions of `tile` (out of range = zero border)
             const int n = tile >> 2, band = tile & 3;
@@ -2277,7 +2284,7 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
                 const int rr = q / PW, cc = q - rr * PW;
                 const int y = band * TR + rr - 1, x = cc - 1;
                 const bool ok = q < PP && tile < a.n_tiles && (unsigned)y < 28u && (unsigned)x < 28u;
-                x_voff[i] = ok ? (unsigned)(((n * 28 + y) * 28 + x) * 128 + (slot ^ (q & 7)) * 8) * 2u : kOobOffset;
+                x_voff[i] = (ok && !(B2_ABL & 4)) ? (unsigned)(((n * 28 + y) * 28 + x) * 128 + (slot ^ (q & 7)) * 8) * 2u : kOobOffset;
             }
         };
         auto issue_band = [&](int c2) {           // 9 DMAs per wave: chunk c2 of the band decoded last
@@ -2298,7 +2305,7 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
             const int cofs = __builtin_amdgcn_readfirstlane(c * 128);
 #pragma unroll
             for (int i = 0; i < 7; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(smem + RESB_OFF + i * 4096 + lw * 1024), 16, row_voff(i, tile_pix0), cofs, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(smem + RESB_OFF + i * 4096 + lw * 1024), 16, (B2_ABL & 2) ? kOobOffset : row_voff(i, tile_pix0), cofs, 0, 0);
         };
         auto copy_out = [&](unsigned tile_pix0, int c) {        // 7 LDS reads + 7 stores per wave
             const int cofs = __builtin_amdgcn_readfirstlane(c * 128);
@@ -2306,7 +2313,7 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
 #pragma unroll
             for (int i = 0; i < 7; ++i) v[i] = *reinterpret_cast<const u32x4*>(smem + OUTC_OFF + i * 4096 + lt * 16);
 #pragma unroll
-            for (int i = 0; i < 7; ++i) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, row_voff(i, tile_pix0), cofs, 0);
+            for (int i = 0; i < 7; ++i) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, (B2_ABL & 2) ? kOobOffset : row_voff(i, tile_pix0), cofs, 0);
         };
         int ring = 0;                             // ring slot of the next stage to issue
         auto stage_issue = [&](int p) {           // stage p (0 .. SPT-1) of a tile; 4 DMAs per wave
@@ -2421,7 +2428,10 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
 #pragma unroll
                 for (int t = 0; t < NS; ++t) {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) ac[m][t % NB] = mfma_e<ET>(t >= NB ? wg[m] : wf[m], x[t], ac[m][t % NB]);
+                    for (int m = 0; m < 2; ++m) {
+                        if constexpr (B2_ABL & 1) { asm volatile("" ::"v"(t >= NB ? wg[m] : wf[m]), "v"(x[t])); }
+                        else ac[m][t % NB] = mfma_e<ET>(t >= NB ? wg[m] : wf[m], x[t], ac[m][t % NB]);
+                    }
                     if (t + PD < NS) x[t + PD] = *reinterpret_cast<const bf16x8*>(xaddr(t + PD));
                 }
                 __builtin_amdgcn_sched_group_barrier(0x100, 4 + PD, 0);
