@@ -2213,7 +2213,8 @@ struct Block2Args {
 };
 
 // Diagnostic ablations (scripts/build_variant.sh -DB2_ABL=mask; timing only, results are wrong): 1 = no MFMAs (reads stay live),
-// 2 = identity DMAs zero-fill and the block output is not stored, 4 = band DMAs zero-fill, 8 = weight-stage DMAs zero-fill
+// 2 = identity DMAs zero-fill and the block output is not stored, 4 = band DMAs zero-fill, 8 = weight-stage DMAs zero-fill,
+// 16 = the loaders issue neither identity DMAs nor the copy-out (no instructions at all)
 #ifndef B2_ABL
 #define B2_ABL 0
 #endif
@@ -2297,23 +2298,27 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
         // tile, 16-B chunk slot ^ (R & 7) of the 64-channel chunk): identity rows by LDS-DMA into RESB one chunk ahead, out_c copied
         // from OUTC to HBM with 16-B stores -- the consumers' own accesses would be MFMA-fragment shaped (16 rows x 64 B per
         // instruction), several times the address-unit cost per byte
-        auto row_voff = [&](int i, unsigned tile_pix0) -> unsigned {
+        // per-lane part of the row offsets, fixed for the launch (rows past the tile's 196: out of range); the tile and the chunk go into
+        // the scalar offset, so the loop issues these 7 + 7 + 7 instructions without any vector arithmetic
+        unsigned rv[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
             const int R = 32 * i + srow;
-            return R < NPX ? ((tile_pix0 + (unsigned)R) * 512u + (unsigned)((slot ^ (R & 7)) * 8)) * 2u : kOobOffset;
-        };
+            rv[i] = (R < NPX && !(B2_ABL & 2)) ? ((unsigned)R * 512u + (unsigned)((slot ^ (R & 7)) * 8)) * 2u : kOobOffset;
+        }
         auto issue_res = [&](unsigned tile_pix0, int c) {       // 7 DMAs per wave
-            const int cofs = __builtin_amdgcn_readfirstlane(c * 128);
+            const int sofs = __builtin_amdgcn_readfirstlane((int)(tile_pix0 * 1024u) + c * 128);
 #pragma unroll
             for (int i = 0; i < 7; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(smem + RESB_OFF + i * 4096 + lw * 1024), 16, (B2_ABL & 2) ? kOobOffset : row_voff(i, tile_pix0), cofs, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(smem + RESB_OFF + i * 4096 + lw * 1024), 16, rv[i], sofs, 0, 0);
         };
         auto copy_out = [&](unsigned tile_pix0, int c) {        // 7 LDS reads + 7 stores per wave
-            const int cofs = __builtin_amdgcn_readfirstlane(c * 128);
+            const int sofs = __builtin_amdgcn_readfirstlane((int)(tile_pix0 * 1024u) + c * 128);
             u32x4 v[7];
 #pragma unroll
             for (int i = 0; i < 7; ++i) v[i] = *reinterpret_cast<const u32x4*>(smem + OUTC_OFF + i * 4096 + lt * 16);
 #pragma unroll
-            for (int i = 0; i < 7; ++i) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, (B2_ABL & 2) ? kOobOffset : row_voff(i, tile_pix0), cofs, 0);
+            for (int i = 0; i < 7; ++i) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, rv[i], sofs, 0);
         };
         int ring = 0;                             // ring slot of the next stage to issue
         auto stage_issue = [&](int p) {           // stage p (0 .. SPT-1) of a tile; 4 DMAs per wave
@@ -2377,14 +2382,22 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
                 if (p == PBAND && has_next) { decode_band(tile + grid); issue_band(0); if (C1N) younger = 0; else younger += XPASS; }
                 const bool bpos = C1N && p > NCONV && ((p - NCONV) & 1) == 1;      // B stage of chunk (p - 19) / 2
                 // identity rows of the NEXT chunk (chunk 0: two stages before the first A stage): needed one barrier later
-                if (C1N && p == NCONV - 2) { issue_res(tile_pix0, 0); younger += 7; }
-                if (bpos && p + 1 < SPT) { issue_res(tile_pix0, (p - NCONV + 1) / 2); younger += 7; }
+                if (C1N && p == NCONV - 2 && !(B2_ABL & 16)) { issue_res(tile_pix0, 0); younger += 7; }
+                if (bpos && p + 1 < SPT && !(B2_ABL & 16)) { issue_res(tile_pix0, (p - NCONV + 1) / 2); younger += 7; }
                 const bool st = (p + 2 < SPT) || has_next;
                 if (st) { stage_issue(p + 2 < SPT ? p + 2 : p + 2 - SPT); younger += WPASS; }
-                if (bpos) {                       // out_c is complete (the extra barrier above): LDS -> HBM; the stores are not waited for here
-                    copy_out(tile_pix0, (p - NCONV) / 2);
+                // What the loaders do per iteration has to stay below what the consumers do per stage (~1,000-1,400 cycles), or every barrier
+                // waits for the loaders (-DB2_ABL=16: without the identity / copy-out instructions the launch takes 123 us instead of 158).
+                // out_c(c) is complete behind the extra barrier in front of B(c) and stays intact until E(c + 1), i.e. over two iterations:
+                // its copy-out (LDS -> HBM) goes into the SECOND one, the A(c + 1) position, which carries nothing but a weight stage (with
+                // identity DMAs, stage and copy-out all in the B position: 155 us; so: 145 us).  Chunk 7 has no A position behind it: copied
+                // at its own B position.  (Also tried: identity rows and the next band prefetched into loader REGISTERS two iterations
+                // early and written to LDS when the buffer falls free, instead of an LDS-DMA issued at that moment: 155 us, slower.)
+                const bool cpos = C1N && !(B2_ABL & 16) && p > NCONV + 1 && (((p - NCONV) & 1) == 0 || p == SPT - 1);
+                if (cpos) {                       // the stores are not waited for here, nor at the next iteration (whose wait covers this iteration's DMAs)
+                    copy_out(tile_pix0, p == SPT - 1 ? 7 : (p - NCONV) / 2 - 1);
                     younger += 7;
-                    carry = 7;                    // ... nor at the next iteration, whose wait covers this iteration's DMAs
+                    carry = 7;
                 }
                 wait_younger(younger);            // stage p + 1, the band chunk / identity rows due now and everything older landed
                 __builtin_amdgcn_s_barrier();
