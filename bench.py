@@ -200,6 +200,7 @@ def main() -> None:
     ap.add_argument("--no-ds-cat", action="store_true", help="A/B: downsample conv and conv3 of layer2.0 / 3.0 / 4.0 as separate launches")
     ap.add_argument("--no-overlap-ds", action="store_true", help="A/B: downsample convs on the main stream")
     ap.add_argument("--no-block2", action="store_true", help="A/B: layer2.1-.3 as conv2 launch + fused tail instead of one launch per bottleneck body")
+    ap.add_argument("--block1", type=int, default=-1, help="A/B: option fuse_block1 (0 = layer1 as conv2 launch + fused tail, 1 = layer1.1 in one launch, 2 = layer1.2 too)")
     ap.add_argument("--inplace", action="store_true", help="A/B: plain-identity blocks write their output over their input (same bits; measured: no gain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat", type=float, default=1.0,
@@ -262,6 +263,8 @@ def main() -> None:
         bb.set_option("inplace_out", 1)
     if args.no_block2:
         bb.set_option("fuse_block2", 0)
+    if args.block1 >= 0:
+        bb.set_option("fuse_block1", args.block1)
     x = synthetic_frames(args.batch, seed=1234 + rank).to(dev)          # random data, resident in HBM
     run = bb.features
     if args.input == "u8":

@@ -2618,6 +2618,332 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Bottleneck BODY (layer1.1 / layer1.2), one launch per block: conv2 3x3 (64 -> 64) + bn2 + ReLU, conv3 1x1 (64 -> 256) + bn3 +
+// identity + ReLU and the NEXT block's conv1 1x1 (256 -> C1N: 64, or 128 = layer2.0.conv1) + bn1 + ReLU.  Same idea as
+// bneck_block2_kernel: t2 never leaves the CU (1.03 GB of HBM traffic per block at batch 256 instead of 1.23) and one launch
+// instead of two.  At 56x56 the block is bound by what a CU can stream (1.3 KB per pixel against 0.14 MFLOP), so what matters is that the
+// loaders keep identity rows, output rows and the next band moving while the consumers run the three small GEMMs beside them.
+// Tile = a band of 4 rows x 56 columns of one image = 224 pixels = 14 MFMA column blocks (14 tiles per image).  Every GEMM here is
+// 64 rows wide: 8 consumer waves = 2 cout groups (32 rows) x 4 pixel quarters (4 + 4 + 3 + 3 blocks), 4 loader waves.
+// Stream of 8-KB weight stages [64 rows][64 K] through a ring of three: conv2: 9 (taps; the band, with halo, is resident);
+// per 64-channel chunk c of the block output: A(c): W3[64 c ..] against T2; E(c): + identity, ReLU -> OUTC;
+// B(c): W1[.., 64 c ..] against OUTC (C1N = 128: two stages, cout halves); then next t1 = relu(accB).
+// Summation orders are those of conv3x3_c64_kernel (taps ascending, K halves inside) and of the igemm launches (bias first, K
+// ascending, identity last): bit-identical outputs.
+// LDS: XB 45,056 (348 padded positions x 128 B) | T2 28,672 | OUTC 28,672 | RESB 28,672 | ring 3 x 8,192 | biases 1,792 = 157,440 B.
+// ------------------------------------------------------------------------------------------------
+struct Block1Args {
+    const __bf16* t1;     // (N,56,56,64)   this block's conv1 output
+    const __bf16* w2;     // (64, 3, 3, 64) folded conv2 weights, K-major (tap, cin)
+    const float* b2;      // (64)
+    const __bf16* w3;     // (256, 64)
+    const float* b3;      // (256)
+    const __bf16* res;    // (M, 256)  identity
+    __bf16* out;          // (M, 256)  block output
+    const __bf16* w1;     // (C1N, 256) next conv1
+    const float* b1;      // (C1N)
+    __bf16* y1n;          // (M, C1N)
+    int N;
+    int n_tiles;          // 14 N
+};
+
+template <int ET, int C1N>
+__global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(C1N == 64 || C1N == 128, "next conv1: 256 -> 64 or 256 -> 128");
+    constexpr int IW = 56, TR = 4, PW = IW + 2, PP = (TR + 2) * PW;       // 348 padded positions
+    constexpr int XPASS = (PP + 31) / 32, XBUF = XPASS * 32 * 128;        // 11 passes, 45,056 B
+    constexpr int NPX = TR * IW;                                          // 224 = 7 passes of 32 rows
+    constexpr int SLOT = NPX * 128;                                       // 28,672
+    constexpr int XB_OFF = 0, T2_OFF = XBUF, OUTC_OFF = T2_OFF + SLOT, RESB_OFF = OUTC_OFF + SLOT, RING_OFF = RESB_OFF + SLOT;
+    constexpr int NST = 3, WSTAGE = 64 * 128, WPASS = 2;
+    constexpr int BIAS_OFF = RING_OFF + NST * WSTAGE;                     // b2 (64) | b3 (256) | b1 (C1N) floats
+    constexpr int NB1 = C1N / 64;                                         // B stages per chunk
+    constexpr int NCONV = 9, LCH = 1 + NB1, SPT = NCONV + 4 * LCH;        // 17 / 21 stages per tile
+    static_assert(BIAS_OFF + 448 * 4 <= 163840, "LDS map");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grid = gridDim.x, first = blockIdx.x;
+
+    if (tid < 64 + 256 + C1N) {
+        float v;
+        if (tid < 64) v = a.b2[tid];
+        else if (tid < 320) v = a.b3[tid - 64];
+        else v = a.b1[tid - 320];
+        reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = v;
+    }
+
+    if (wave >= 8) {
+        // =============================== loader waves ===============================================
+        const int lw = wave - 8, lt = tid - 512;
+        const int srow = lt >> 3, slot = lt & 7;
+        const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w2), 0, 64u * 576u * 2u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w3), 0, 256u * 64u * 2u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w1), 0, (unsigned)C1N * 256u * 2u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.t1), 0, (unsigned)a.N * (3136u * 128u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.N * (3136u * 512u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.N * (3136u * 512u), 0x00020000);
+        unsigned w2v[WPASS], w3v[WPASS], w1v[WPASS], x_voff[XPASS], rv[7];
+#pragma unroll
+        for (int i = 0; i < WPASS; ++i) {
+            const int rho = i * 32 + srow;                               // LDS row of the stage (< 64)
+            const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+            const unsigned ch = (unsigned)((slot ^ (rho & 7)) * 8);
+            w2v[i] = ((unsigned)cl * 576u + ch) * 2u;
+            w3v[i] = ((unsigned)cl * 64u + ch) * 2u;
+            w1v[i] = ((unsigned)cl * 256u + ch) * 2u;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {             // rows of a 64-channel chunk of the identity / block output: row R = 32 i + srow of the tile
+            const int R = 32 * i + srow;
+            rv[i] = ((unsigned)R * 256u + (unsigned)((slot ^ (R & 7)) * 8)) * 2u;
+        }
+        auto decode_band = [&](int tile) {        // source offsets of the padded positions of `tile` (out of range = zero border)
+            const int n = tile / 14, tr = tile - n * 14;
+#pragma unroll
+            for (int i = 0; i < XPASS; ++i) {
+                const int q = i * 32 + srow;
+                const int rr = q / PW, cc = q - rr * PW;
+                const int y = tr * TR + rr - 1, x = cc - 1;
+                const bool ok = q < PP && tile < a.n_tiles && (unsigned)y < 56u && (unsigned)x < 56u;
+                x_voff[i] = ok ? (unsigned)(((n * 56 + y) * 56 + x) * 64 + (slot ^ (q & 7)) * 8) * 2u : kOobOffset;
+            }
+        };
+        auto issue_band = [&](int i0, int i1) {   // passes [i0, i1) of the band decoded last
+#pragma unroll
+            for (int i = 0; i < XPASS; ++i)
+                if (i >= i0 && i < i1)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + XB_OFF + i * 4096 + lw * 1024), 16, x_voff[i], 0, 0, 0);
+        };
+        auto issue_res = [&](unsigned tile_pix0, int c) {       // 7 DMAs per wave: identity rows of chunk c
+            const int sofs = __builtin_amdgcn_readfirstlane((int)(tile_pix0 * 512u) + c * 128);
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(smem + RESB_OFF + i * 4096 + lw * 1024), 16, rv[i], sofs, 0, 0);
+        };
+        auto copy_out = [&](unsigned tile_pix0, int c) {        // 7 LDS reads + 7 stores per wave: out_c -> block output
+            const int sofs = __builtin_amdgcn_readfirstlane((int)(tile_pix0 * 512u) + c * 128);
+            u32x4 v[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) v[i] = *reinterpret_cast<const u32x4*>(smem + OUTC_OFF + i * 4096 + lt * 16);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, rv[i], sofs, 0);
+        };
+        int ring = 0;                             // ring slot of the next stage to issue
+        auto stage_issue = [&](int p) {           // stage p (0 .. SPT-1) of a tile; 2 DMAs per wave
+            char* sbase = smem + RING_OFF + ring * WSTAGE + lw * 1024;
+            ring = (ring == NST - 1) ? 0 : ring + 1;
+            if (p < NCONV) {
+                const int sofs = __builtin_amdgcn_readfirstlane(p * 64 * 2);
+#pragma unroll
+                for (int i = 0; i < WPASS; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (LDS_AS void*)(sbase + i * 4096), 16, w2v[i], sofs, 0, 0);
+            } else {
+                const int q = p - NCONV, c = q / LCH, r = q - c * LCH;
+                if (r == 0) {
+                    const int sofs = __builtin_amdgcn_readfirstlane(c * 64 * 64 * 2);
+#pragma unroll
+                    for (int i = 0; i < WPASS; ++i)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (LDS_AS void*)(sbase + i * 4096), 16, w3v[i], sofs, 0, 0);
+                } else {
+                    const int sofs = __builtin_amdgcn_readfirstlane(((r - 1) * 64 * 256 + c * 64) * 2);
+#pragma unroll
+                    for (int i = 0; i < WPASS; ++i)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (LDS_AS void*)(sbase + i * 4096), 16, w1v[i], sofs, 0, 0);
+                }
+            }
+        };
+        auto wait_younger = [&](int n) {          // all but the n youngest vector-memory operations of this wave are complete
+            bool done = false;
+#pragma unroll
+            for (int e = 1; e <= 40; ++e)
+                if (!done && n == e) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(e) : "memory"); done = true; }
+            if (!done) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        };
+        decode_band(first);
+        issue_band(0, XPASS);
+        stage_issue(0);
+        stage_issue(1);
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");       // band and stage 0 landed (stage 1 may be in flight); bias writes done
+        __builtin_amdgcn_s_barrier();
+        int carry = 0;                            // stores of the previous iteration (issued behind its DMAs)
+#pragma unroll 1
+        for (int tile = first; tile < a.n_tiles; tile += grid) {
+            const bool has_next = tile + grid < a.n_tiles;
+            const unsigned tile_pix0 = (unsigned)((tile / 14) * 3136 + (tile % 14) * NPX);
+#pragma unroll 1
+            for (int p = 0; p < SPT; ++p) {
+                const int q = p - NCONV, c = q >= 0 ? q / LCH : -1, r = q >= 0 ? q - c * LCH : -1;
+                // the consumers' extra barriers: T2 complete (in front of the first A stage), OUTC(c) complete (in front of the first B stage)
+                if (p == NCONV || r == 1) __builtin_amdgcn_s_barrier();
+                int younger = carry;
+                carry = 0;
+                // identity rows: chunk 0 two stages before the first A stage (RESB is free since the previous tile's last E), chunk c + 1
+                // right behind E(c) -- they have to be in LDS one barrier later (A(c + 1)), or two (C1N = 128)
+                if (p == NCONV - 2) { issue_res(tile_pix0, 0); younger += 7; }
+                if (r == 1 && c < 3) { issue_res(tile_pix0, c + 1); younger += 7; }
+                // the next tile's band: its buffer is dead once conv2 is done (behind the T2 barrier); spread over the tail's first positions
+                if (has_next && p >= NCONV && p < NCONV + 4) {
+                    if (p == NCONV) decode_band(tile + grid);
+                    const int i0 = 3 * (p - NCONV), i1 = (p == NCONV + 3) ? XPASS : i0 + 3;
+                    issue_band(i0, i1);
+                    younger += i1 - i0;
+                }
+                const bool st = (p + 2 < SPT) || has_next;
+                if (st) { stage_issue(p + 2 < SPT ? p + 2 : p + 2 - SPT); younger += WPASS; }
+                // out_c(c), complete behind the OUTC barrier, is intact until E(c + 1): copied out one position later (C1N = 64: the A(c + 1)
+                // position; C1N = 128: the second B position), chunk 3 at the tile's last position
+                const bool cpos = (C1N == 64) ? ((r == 0 && c >= 1) || p == SPT - 1) : (r == 2);
+                if (cpos) {
+                    copy_out(tile_pix0, (C1N == 64 && p != SPT - 1) ? c - 1 : c);
+                    younger += 7;
+                    carry = 7;
+                }
+                wait_younger(younger);            // stage p + 1 and everything older (identity rows, band passes) landed
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    } else {
+        // =============================== consumer waves =============================================
+        const int wave_a = wave & 1, wave_q = wave >> 1;                 // cout group (32 of 64), pixel quarter: blocks 0-3, 4-7, 8-10, 11-13
+        const int qb0 = wave_q < 2 ? 4 * wave_q : 8 + 3 * (wave_q - 2);
+        const int fr = lane & 15, fq = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.N * (3136u * C1N * 2u), 0x00020000);
+        const int w_row = (wave_a * 32 + fr) * 128;                       // + m * 2048
+        const int w_ph0 = (fq ^ (fr & 7)) << 4;                          // kk = 0; kk = 1 is ^ 64
+        const int ch_lane = wave_a * 32 + 8 * fq;                        // this lane's 8 consecutive channels of a 64-channel group
+        // pixel row p = p0 + 16 j of block j: B fragment (kk = 0) at pb0 + 2048 j of a K-slot (p & 7 does not depend on j); kk = 1 is ^ 64;
+        // this lane's 8 channels of that row (as the B operand of the NEXT GEMM, or the identity's): (pb0 + 2048 j) ^ cf_x
+        const int p0 = 16 * qb0 + fr, pb0 = p0 * 128 + ((fq ^ (p0 & 7)) << 4), cf_x = wave_a << 6;
+
+        auto run = [&](auto nq_c) {
+            constexpr int NQ = decltype(nq_c)::value;
+            f32x4 acc[2][NQ], accB[NB1][2][NQ];
+            int cbuf = 0;
+            auto gemm64 = [&](const char* wb, auto xaddr, auto& ac) {
+                constexpr int NS = 2 * NQ, PD = 3;
+                bf16x8 x[NS], wf[2], wg[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(wb + m * 2048 + w_ph0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) wg[m] = *reinterpret_cast<const bf16x8*>(wb + m * 2048 + (w_ph0 ^ 64));
+#pragma unroll
+                for (int t = 0; t < PD; ++t) x[t] = *reinterpret_cast<const bf16x8*>(xaddr(t));
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) ac[m][t % NQ] = mfma_e<ET>(t >= NQ ? wg[m] : wf[m], x[t], ac[m][t % NQ]);
+                    if (t + PD < NS) x[t + PD] = *reinterpret_cast<const bf16x8*>(xaddr(t + PD));
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 + PD, 0);
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    if (t + PD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto stage_done = [&]() {             // the barrier stays behind the stage's last fragment read
+                cbuf = (cbuf == NST - 1) ? 0 : cbuf + 1;
+                __builtin_amdgcn_s_barrier();
+            };
+            auto pack_relu = [&](const f32x4& lo, const f32x4& hi) {
+                u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                return o;
+            };
+            auto set_bias = [&](f32x4 (&ac)[2][NQ], int fidx) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (fidx + ch_lane) * 4);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (fidx + ch_lane + 4) * 4);
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) { ac[0][j] = lo; ac[1][j] = hi; }
+            };
+#pragma unroll 1
+            for (int tile = first; tile < a.n_tiles; tile += grid) {
+                const unsigned pix0 = (unsigned)((tile / 14) * 3136 + (tile % 14) * NPX + p0);       // + 16 j
+                // ---- conv2: bias, then 9 stages (taps) against the resident band
+                set_bias(acc, 0);
+                {
+                    int opq = 0;                  // (keeps the per-tile position table out of the registers that live across the tile loop)
+                    asm volatile("" : "+v"(opq));
+                    int q0[NQ];
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const int p = p0 + 16 * j + opq;
+                        const int r = p / IW, c = p - r * IW;
+                        q0[j] = r * PW + c;
+                    }
+#pragma unroll 1
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int kh = (tap >= 6) ? 2 : (tap >= 3) ? 1 : 0, kw = tap - 3 * kh;
+                        const int toff = kh * PW + kw;
+                        gemm64(smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) {
+                            const int row = q0[t % NQ] + toff;
+                            return smem + XB_OFF + row * 128 + ((((t >= NQ ? 4 : 0) + fq) ^ (row & 7)) << 4);
+                        }, acc);
+                        stage_done();
+                    }
+                }
+                // ---- t2 = relu(acc) -> T2
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) *reinterpret_cast<u32x4*>(smem + T2_OFF + ((pb0 + 2048 * j) ^ cf_x)) = pack_relu(acc[0][j], acc[1][j]);
+#pragma unroll
+                for (int h = 0; h < NB1; ++h) set_bias(accB[h], 320 + 64 * h);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                   // T2 complete
+#pragma unroll 1
+                for (int c = 0; c < 4; ++c) {
+                    set_bias(acc, 64 + 64 * c);
+                    // ---- A(c): W3[64 c ..] . t2
+                    gemm64(smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) { return smem + T2_OFF + ((pb0 + 2048 * (t % NQ)) ^ (t >= NQ ? 64 : 0)); }, acc);
+                    stage_done();
+                    // ---- E(c): + identity (RESB, landed with this stage's barrier), ReLU, 16 bit -> OUTC: the block output's chunk (the loaders
+                    //      copy it out) and the next conv1's K-slice
+                    {
+                        u32x4 rr[NQ];
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j) rr[j] = *reinterpret_cast<const u32x4*>(smem + RESB_OFF + ((pb0 + 2048 * j) ^ cf_x));
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j) {
+                            f32x4 lo = acc[0][j], hi = acc[1][j];
+                            lo[0] += unpack_lo_e<ET>(rr[j][0]); lo[1] += unpack_hi_e<ET>(rr[j][0]);
+                            lo[2] += unpack_lo_e<ET>(rr[j][1]); lo[3] += unpack_hi_e<ET>(rr[j][1]);
+                            hi[0] += unpack_lo_e<ET>(rr[j][2]); hi[1] += unpack_hi_e<ET>(rr[j][2]);
+                            hi[2] += unpack_lo_e<ET>(rr[j][3]); hi[3] += unpack_hi_e<ET>(rr[j][3]);
+                            *reinterpret_cast<u32x4*>(smem + OUTC_OFF + ((pb0 + 2048 * j) ^ cf_x)) = pack_relu(lo, hi);
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();               // OUTC(c) complete
+                    // ---- B(c): W1[64 h .., 64 c ..] . out_c into the next conv1's accumulators
+#pragma unroll
+                    for (int h = 0; h < NB1; ++h) {
+                        gemm64(smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) { return smem + OUTC_OFF + ((pb0 + 2048 * (t % NQ)) ^ (t >= NQ ? 64 : 0)); }, accB[h]);
+                        stage_done();
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < NB1; ++h)
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const u32x4 o = pack_relu(accB[h][0][j], accB[h][1][j]);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, ((pix0 + 16 * j) * (unsigned)C1N + (unsigned)(64 * h + ch_lane)) * 2u, 0, 0);
+                    }
+            }
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's part of the biases is in LDS ...
+        __builtin_amdgcn_s_barrier();                           // ... and so is everybody's; band + stage 0 landed
+        if (wave_q < 2) run(std::integral_constant<int, 4>{});
+        else run(std::integral_constant<int, 3>{});
+    }
+#else
+    (void)a;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Frame producer: crop box + bilinear resize of decoded uint8 frames, on the device.
 // Reference: _crop_and_resize_video_uint8 (src/dataset.py:141-149) = slice [top:top+hh, left:left+ww] of the
 // (T,H,W,3) clip, then torchvision resize(..., [224,224], antialias=False) on uint8, which on an AVX2 CPU is ATen's

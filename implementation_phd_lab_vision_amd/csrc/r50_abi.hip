@@ -69,6 +69,7 @@ struct r50_handle {
     int fuse_fp8_handover = 1;          // fp8 mode: quantise layer1's output in layer1.2.conv3's epilogue instead of in a pass of its own
     int fuse_tail3 = 1;                 // layer3.1-.4: conv3 + identity + ReLU chained with the next block's conv1 through LDS (bneck_tail3_kernel)
     __bf16* tail3_wp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per layer3 block b: [W3(b) | W1(b+1)] in the kernel's fragment order
+    int fuse_block1 = 1;                // layer1.1 (2: also layer1.2): the bottleneck body in one launch (bneck_block1_kernel)
     int fuse_block2 = 1;                // layer2.1-.3: the whole bottleneck body (conv2 + conv3 + identity + ReLU [+ next conv1]) in one launch
     int inplace_out = 0;                // plain-identity blocks write their output over their input (same bits, fewer DRAM page switches)
     int n_streams = 1;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
@@ -771,6 +772,31 @@ hipError_t launch_bneck_block2(const void* t1, int n, const void* w2, const floa
     return hipGetLastError();
 }
 
+// layer1.1 / .2 bottleneck body in one launch (kernels.h: bneck_block1_kernel): conv2 + conv3 + identity + ReLU + the next conv1 (c1 = 64 or 128)
+hipError_t launch_bneck_block1(const void* t1, int n, const void* w2, const float* b2, const void* w3, const float* b3, const void* res,
+                               void* out, const void* w1, int c1, const float* b1, void* y1n, hipStream_t s, int et = 0) {
+    if (!t1 || !w2 || !b2 || !w3 || !b3 || !res || !out || !w1 || !b1 || !y1n || n <= 0 || (long long)n * 3136 * 512 >= (1ll << 31)) return hipErrorInvalidValue;
+    if (c1 != 64 && c1 != 128) return hipErrorInvalidValue;
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        g_num_cus = cu_budget(prop.multiProcessorCount);
+    }
+    Block1Args a;
+    a.t1 = (const __bf16*)t1; a.w2 = (const __bf16*)w2; a.b2 = b2; a.w3 = (const __bf16*)w3; a.b3 = b3; a.res = (const __bf16*)res;
+    a.out = (__bf16*)out; a.w1 = (const __bf16*)w1; a.b1 = b1; a.y1n = (__bf16*)y1n; a.N = n; a.n_tiles = 14 * n;
+    const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
+    constexpr size_t lds = 11 * 32 * 128 + 3 * 224 * 128 + 3 * 8192 + 448 * 4;       // 157,440 (kernels.h: LDS map)
+    void (*kern)(const Block1Args);
+    if (c1 == 64) kern = et == 1 ? bneck_block1_kernel<1, 64> : bneck_block1_kernel<0, 64>;
+    else kern = et == 1 ? bneck_block1_kernel<1, 128> : bneck_block1_kernel<0, 128>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, s, a);
+    return hipGetLastError();
+}
+
 // q_inv > 0: write the output as e4m3 = fp8(16-bit result * q_inv) (role-specialised tiles only; *q_done reports whether that happened)
 int run_conv(r50_handle* h, const ConvLayer& L, const __bf16* x, int n, int hh, int ww, const __bf16* res,
              __bf16* y, int relu, hipStream_t s, int* ho, int* wo, float q_inv = 0.f, bool* q_done = nullptr) {
@@ -1172,6 +1198,29 @@ after_pool:
             const bool block2 = h->fuse_block2 && h->fuse_tail && !split && !tap && si == 1 && b > 0 && h->tile_override == 0 && !ds_side &&
                                 (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16) && hh == 28 && ww == 28 && c1.cout == 128 &&
                                 c2.ks == 3 && c2.stride == 1 && c2.pad == 1 && c2.cin == 128 && c2.cout == 128 && c3.ks == 1 && c3.cin == 128 && c3.cout == 512;
+            // layer1.1 (and, option "fuse_block1" = 2, layer1.2): the same for the 56x56 / 64-channel body (kernels.h: bneck_block1_kernel)
+            const bool nx64 = nx && nx->ks == 1 && nx->stride == 1 && nx->cin == 256 && (nx->cout == 64 || (nx->cout == 128 && h->fuse_block1 >= 2));
+            const bool block1 = h->fuse_block1 && h->fuse_tail && !split && !tap && si == 0 && b > 0 && h->tile_override == 0 && nx64 &&
+                                (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16 || (h->precision == R50_PREC_FP8 && nx->cout == 64)) &&
+                                hh == 56 && ww == 56 && c1.cout == 64 && c2.ks == 3 && c2.stride == 1 && c2.pad == 1 && c2.cin == 64 && c2.cout == 64 &&
+                                c3.ks == 1 && c3.cin == 64 && c3.cout == 256;
+            if (block1) {
+                if (!have_t1) {
+                    rc = run_conv(h, c1, buf[cur], n, hh, ww, nullptr, buf[fr[0]], 1, s, &h1, &w1);
+                    if (rc) return rc;
+                }
+                const double m = (double)n * 3136.0;
+                EvRec rb{};
+                prof_begin(h, s, rb, PC_BLOCK2, 2.0 * m * (64.0 * 576 + 256.0 * 64 + (double)nx->cout * 256),
+                           2.0 * (m * (64.0 + 256 + 256 + nx->cout) + 64.0 * 576 + 256.0 * 64 + (double)nx->cout * 256), (int)(&c2 - &h->convs[0]));
+                e = launch_bneck_block1(buf[fr[0]], n, c2.w, c2.bias, c3.w, c3.bias, buf[cur], buf[fr[3]], nx->w, nx->cout, nx->bias, buf[fr[1]], s, et);
+                prof_end(h, s, rb);
+                if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_block1 launch (" + c2.conv_key + "): " + hipGetErrorString(e));
+                pre_t1 = fr[1];
+                cur = fr[3];
+                li += 3;
+                continue;
+            }
             if (block2) {
                 if (!have_t1) {
                     rc = run_conv(h, c1, buf[cur], n, hh, ww, nullptr, buf[fr[0]], 1, s, &h1, &w1);
@@ -1620,6 +1669,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "streams") { if (value < 1 || value > 4) return fail(h, R50_ERR_INVALID, "streams must be in [1,4]"); h->n_streams = (int)value; }
     else if (k == "inplace_out") h->inplace_out = value ? 1 : 0;
     else if (k == "fuse_block2") h->fuse_block2 = value ? 1 : 0;
+    else if (k == "fuse_block1") { if (value < 0 || value > 2) return fail(h, R50_ERR_INVALID, "fuse_block1 must be 0, 1 or 2"); h->fuse_block1 = (int)value; }
     else if (k == "xres_variant") g_xres_variant = (int)value;        // process-wide A/B knob
     else if (k == "cu_cap") { if (value < 0 || value > 4096) return fail(h, R50_ERR_INVALID, "cu_cap must be in [0,4096]"); g_cu_cap = (int)value; g_num_cus = 0; }
     else return fail(h, R50_ERR_INVALID, "r50_set_option: unknown key " + k);
@@ -1636,6 +1686,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "cu_cap") *value = g_cu_cap;
     else if (k == "inplace_out") *value = h->inplace_out;
     else if (k == "fuse_block2") *value = h->fuse_block2;
+    else if (k == "fuse_block1") *value = h->fuse_block1;
     else if (k == "fused_stem") *value = h->fused_stem;
     else if (k == "fuse_tail") *value = h->fuse_tail;
     else if (k == "fuse_tail3") *value = h->fuse_tail3;
@@ -1795,6 +1846,14 @@ int r50_op_bneck_block2(const void* t1, int n, const void* w2, const float* b2, 
     const hipError_t e = launch_bneck_block2(t1, n, w2, b2, w3, b3, res, out, w1, b1, y1n, (hipStream_t)stream);
     if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
                                      std::string("r50_op_bneck_block2: ") + hipGetErrorString(e));
+    return R50_OK;
+}
+
+int r50_op_bneck_block1(const void* t1, int n, const void* w2, const float* b2, const void* w3, const float* b3, const void* res,
+                        void* out, const void* w1, int c1, const float* b1, void* y1n, void* stream) {
+    const hipError_t e = launch_bneck_block1(t1, n, w2, b2, w3, b3, res, out, w1, c1, b1, y1n, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
+                                     std::string("r50_op_bneck_block1: ") + hipGetErrorString(e));
     return R50_OK;
 }
 

@@ -205,6 +205,29 @@ def bneck_block2_bf16(t1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, w3: 
     return out, y1n
 
 
+def bneck_block1_bf16(t1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, identity: torch.Tensor,
+                      w1: torch.Tensor, b1: torch.Tensor):
+    """Layer1 bottleneck body in one launch (``r50_op_bneck_block1``): t1 (N,56,56,64), identity (N,56,56,256) bf16 NHWC; w2 (64,3,3,64),
+    w3 (256,64), w1 (c1,256) bf16 with c1 in {64, 128}; biases fp32.  Returns (block output (N,56,56,256), next t1 (N,56,56,c1))."""
+    for t, name in ((t1, "t1"), (w2, "w2"), (w3, "w3"), (identity, "identity"), (w1, "w1")):
+        _need(t, torch.bfloat16, name)
+    _need(b2, torch.float32, "b2"); _need(b3, torch.float32, "b3"); _need(b1, torch.float32, "b1")
+    n = t1.shape[0]
+    c1 = w1.shape[0]
+    if tuple(t1.shape) != (n, 56, 56, 64) or tuple(identity.shape) != (n, 56, 56, 256) or tuple(w2.shape) != (64, 3, 3, 64) \
+            or tuple(w3.shape) != (256, 64) or tuple(w1.shape) != (c1, 256) or c1 not in (64, 128) or b2.numel() != 64 or b3.numel() != 256 \
+            or b1.numel() != c1:
+        raise ValueError("bneck_block1_bf16: inconsistent shapes")
+    out = torch.empty((n, 56, 56, 256), dtype=torch.bfloat16, device=t1.device)
+    y1n = torch.empty((n, 56, 56, c1), dtype=torch.bfloat16, device=t1.device)
+    with torch.cuda.device(t1.device):
+        rc = _lib.load_library().r50_op_bneck_block1(t1.data_ptr(), n, w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(),
+                                                     identity.data_ptr(), out.data_ptr(), w1.data_ptr(), c1, b1.data_ptr(), y1n.data_ptr(),
+                                                     _stream(t1))
+    _lib.check(rc, None, "r50_op_bneck_block1")
+    return out, y1n
+
+
 def stem_bf16(x_nchw: torch.Tensor, w_folded_oihw: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """conv1 7x7 s2 p3 + folded bn1 + ReLU: (N,3,224,224) fp32 NCHW -> (N,112,112,64) bf16 NHWC.
     ``w_folded_oihw``: (64,3,7,7) fp32 on the HOST (already BN-folded); ``bias``: (64) fp32 on the GPU."""

@@ -100,6 +100,7 @@ int r50_forward_layer(r50_handle* h, const float* x_nchw_f32_dev, int n, const c
  * "overlap_ds" (1 = downsample convs on a side stream; default 0), "fused_stem" (default 1),
  * "fuse_tail" (layer1 / layer2: conv3 + identity + ReLU + the next block's conv1 in one kernel; default 1),
  * "fuse_tail3" (layer3.1-.4: the same pair chained through LDS in one launch; default 1; needs "fuse_tail"),
+ * "fuse_block1" (layer1.1: the same for the 56x56 body, bneck_block1_kernel; 2 = layer1.2 as well; default 1; needs "fuse_tail"; same bits),
  * "fuse_block2" (layer2.1-.3: conv2 + conv3 + identity + ReLU [+ the next conv1] in one launch, t2 kept in LDS; default 1; needs
  * "fuse_tail"; same bits),
  * "fuse_fp8_handover" (R50_PREC_FP8: layer1's output quantised to e4m3 in layer1.2.conv3's epilogue instead of in a pass of its
@@ -205,6 +206,12 @@ int r50_op_bneck_tail(const void* y2_bf16, int64_t m, int cmid, const void* w3_b
  * r50_op_conv2d 1x1 launches give.  w1 = b1 = y1n = NULL: no next conv1 (the stage's last block). */
 int r50_op_bneck_block2(const void* t1_bf16, int n, const void* w2_bf16, const float* b2, const void* w3_bf16, const float* b3,
                         const void* identity_bf16, void* out_bf16, const void* w1_bf16, const float* b1, void* y1n_bf16, void* stream);
+
+/* The same for layer1 (blocks .1 / .2, 56x56, 64 mid channels): t1 (n,56,56,64), identity / out (n,56,56,256), w2 (64,3,3,64), w3 (256,64),
+ * w1 (c1,256) with c1 = 64 (the next layer1 block's conv1) or 128 (layer2.0.conv1), y1n (n,56,56,c1).  Bit for bit what the
+ * resident-weights 3x3 launch followed by two r50_op_conv2d 1x1 launches give. */
+int r50_op_bneck_block1(const void* t1_bf16, int n, const void* w2_bf16, const float* b2, const void* w3_bf16, const float* b3,
+                        const void* identity_bf16, void* out_bf16, const void* w1_bf16, int c1, const float* b1, void* y1n_bf16, void* stream);
 
 /* Frame producer, the step before the path: crop box + bilinear resize of a decoded clip on the
  * device.  Replaces `_crop_and_resize_video_uint8` (src/dataset.py:141-149) up to, not including, the `/255`:
