@@ -185,6 +185,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + (bid >> 3);
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform RUNTIME n (the instruction takes an immediate): six scalar compares for 0..63 instead of a
+// linear chain of `if (n == e)` candidates on the loader waves that every barrier of a role-specialised kernel waits for.
+template <int LO, int HI>
+__device__ __forceinline__ void wait_vmcnt_range(int n) {
+    if constexpr (LO == HI) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LO) : "memory");
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (n <= MID) wait_vmcnt_range<LO, MID>(n);
+        else wait_vmcnt_range<MID + 1, HI>(n);
+    }
+}
+__device__ __forceinline__ void wait_vmcnt(int n) { wait_vmcnt_range<0, 63>(n < 0 ? 0 : (n > 63 ? 63 : n)); }
+
 __device__ __forceinline__ unsigned relu_bf16x2(unsigned v) {   // max(x, 0) on two packed bf16 = v_pk_max_i16
     typedef __attribute__((ext_vector_type(2))) short s16x2;
     const s16x2 z = {0, 0};
@@ -2346,13 +2360,7 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
             }
         };
         // all but the n youngest vector-memory operations of this wave are complete
-        auto wait_younger = [&](int n) {
-            bool done = false;
-#pragma unroll
-            for (int e = 1; e <= 27; ++e)
-                if (!done && n == e) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(e) : "memory"); done = true; }
-            if (!done) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        };
+        auto wait_younger = [&](int n) { wait_vmcnt(n); };          // all but the n youngest vector-memory operations of this wave are complete
         decode_band(first);
         issue_band(0);
         issue_band(1);
@@ -2754,13 +2762,7 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
                 }
             }
         };
-        auto wait_younger = [&](int n) {          // all but the n youngest vector-memory operations of this wave are complete
-            bool done = false;
-#pragma unroll
-            for (int e = 1; e <= 40; ++e)
-                if (!done && n == e) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(e) : "memory"); done = true; }
-            if (!done) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        };
+        auto wait_younger = [&](int n) { wait_vmcnt(n); };          // all but the n youngest vector-memory operations of this wave are complete
         decode_band(first);
         issue_band(0, XPASS);
         stage_issue(0);

@@ -7,7 +7,7 @@ cnt = collections.defaultdict(int)
 for f in glob.glob("gpurun_out/pmcb_MFMA/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        cls = "igemm" if ("igemm" in k or "conv3x3_c64" in k or "conv3x3_xres" in k) else "bneck_tail3" if "bneck_tail3" in k else "bneck_tail" if "bneck_tail" in k else \
+        cls = "igemm" if ("igemm" in k or "conv3x3_c64" in k or "conv3x3_xres" in k) else "bneck_block" if "bneck_block" in k else "bneck_tail3" if "bneck_tail3" in k else "bneck_tail" if "bneck_tail" in k else \
               "conv1" if "stem" in k else "avgpool" if "avgpool" in k else None
         if cls is None: continue
         agg[cls][r["Counter_Name"]] += float(r["Counter_Value"])

@@ -10,7 +10,7 @@ for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != cname: continue
             k = r["Kernel_Name"]
-            cls = "igemm" if ("igemm" in k or "conv3x3_c64" in k or "conv3x3_xres" in k) else "bneck_tail3" if "bneck_tail3" in k else "bneck_tail" if "bneck_tail" in k else "conv1" if ("stem_conv" in k or "stem_fused" in k) else "stem_pack" if "stem_pack" in k else \
+            cls = "igemm" if ("igemm" in k or "conv3x3_c64" in k or "conv3x3_xres" in k) else "bneck_block" if "bneck_block" in k else "bneck_tail3" if "bneck_tail3" in k else "bneck_tail" if "bneck_tail" in k else "conv1" if ("stem_conv" in k or "stem_fused" in k) else "stem_pack" if "stem_pack" in k else \
                   "maxpool" if "maxpool" in k else "avgpool" if "avgpool" in k else None
             if cls is None: continue
             a = agg[cls]; a[0] += 1; a[1] += float(r["Counter_Value"]) * 1024.0
