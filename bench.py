@@ -407,7 +407,13 @@ def main() -> None:
                                         "GBps": t3["bytes"] / (t3["ms"] * 1e-3) / 1e9, "frac_of_hbm_peak": t3["bytes"] / (t3["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         b2 = prof.get("bneck_block2")
         if b2 and b2["ms"] > 0:       # layer2.1-.3 bottleneck bodies in one launch each: MFMA work and HBM streaming at once
-            roofline["fourth_kernel"] = {"kernel": "bneck_block2_kernel (%d launches/step)" % round(b2["launches"] / max(1, args.steps)),
+            b_traffic = None
+            try:
+                b_traffic = json.loads(tpath.read_text())["bneck_block"]["hbm_bytes_per_launch"]
+            except Exception:
+                pass
+            roofline["fourth_kernel"] = {"kernel": "bneck_block1_kernel / bneck_block2_kernel (%d launches/step: layer1.1, layer2.1-.3)" % round(b2["launches"] / max(1, args.steps)),
+                                         "traffic": b_traffic, "bytes_per_launch": b2["bytes"] / max(1, b2["launches"]),
                                          "avg_launch_us": 1e3 * b2["ms"] / max(1, b2["launches"]),
                                          "tflops": b2["flops"] / (b2["ms"] * 1e-3) / 1e12, "frac_of_mfma_peak": b2["flops"] / (b2["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                          "GBps": b2["bytes"] / (b2["ms"] * 1e-3) / 1e9, "frac_of_hbm_peak": b2["bytes"] / (b2["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
