@@ -2193,23 +2193,28 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
 // Why: at 28x28 the layer-wise form moves t1 in, t2 out (conv2 launch) and t2 in, identity in, block output out, next t1 out (fused
 // tail): 0.61 GB per block at batch 256.  Here t2 never leaves the CU (0.51 GB: 17 % fewer HBM bytes -- the first-order bound of
 // this network at batch 256 is its 10 GB of HBM traffic per step, not its 2.1 TFLOP) and the block is one launch instead of two.
-// All three GEMMs are 128 wide in their small dimension, so every accumulator set is 128 x 208 fp32 = 56 registers per consumer wave
-// and at most two are live (conv3 chunk + next conv1): the chained form fits the 168-register budget of 12 waves, unlike layer3's.
+// All three GEMMs are 128 wide in their small dimension, so an accumulator set is at most 128 x 208 fp32 = 56 registers per consumer
+// wave and two live sets + fragments fit the 168-register budget of 12 waves (layer3's 256-wide GEMMs do not).
 // Tile = a band of 7 rows x 28 columns of one image = 196 pixels = 13 MFMA column blocks (1024 tiles at batch 256: four per CU).
-// 8 consumer waves (cout group w & 3: 32 rows of every 128-row weight stage; pixel half w >> 2: blocks 0..6 / 7..12) + 4 loader waves.
-// One STREAM of 16-KB weight stages [128 rows][64 K] runs through a ring of three LDS stages, one barrier per stage:
-//     conv2:  18 stages (chunk, tap) of W2 against the tile's t1 band -- both 64-channel chunks of the band, with halo, are resident
-//             in LDS (XB0, XB1), K order (chunk, tap, channel) exactly as conv3x3_xres_kernel: t2 has that kernel's bits
+// 8 consumer waves + 4 loader waves.  One STREAM of 16-KB weight stages runs through a ring of three LDS stages, one barrier per stage:
+//     conv2:  18 stages [128 couts][64 K] (chunk, tap) of W2 against the tile's t1 band -- both 64-channel chunks of the band, with
+//             halo, are resident in LDS (XB0, XB1); K order (chunk, tap, channel) exactly as conv3x3_xres_kernel: t2 has that kernel's
+//             bits.  Waves: cout group w & 3 (32 rows), pixel half w >> 2 (blocks 0..6 / 7..12).
 //     then t2 = relu(acc) -> 16 bit -> LDS (T2: the B operand of conv3, two 64-channel K-slots of 208 pixel rows)
-//     for c in 0..3 (128 block-output channels each):
-//         A(c): 2 stages of W3[128c ..] against T2;   E(c): + identity, ReLU, 16 bit -> block output (HBM) and -> LDS (OUTC)
-//         B(c): 2 stages of W1[:, 128c ..] against OUTC into the next conv1's accumulators, which stay in registers over the chunks
-//     next t1 = relu(accB) -> HBM
+//     C1N = 128, for c in 0..7 (64 block-output channels each; waves: cout group w & 1 (32 rows), pixel quarter w >> 1 (4 + 3 + 3 + 3 blocks)):
+//         A(c): one stage [2 K-slots][64 rows] of W3[64c ..] against T2
+//         E(c): + identity (RESB: DMA'd in by the loaders one chunk ahead, full rows), ReLU, 16 bit -> OUTC = the block output's chunk
+//               (copied to HBM by the loaders at the next A position, full rows) AND the K-slice of the next conv1
+//         B(c): one stage [128 rows][64 K] of W1[:, 64c ..] against OUTC into the next conv1's accumulators (wave split of conv2), which
+//               stay in registers over the chunks;   finally next t1 = relu(accB) -> HBM
+//     C1N = 0 (the stage's last block), for c in 0..3 (128 channels each, wave split of conv2): 2 stages of W3[128c ..] against T2, then the
+//         consumers add the identity and store the block output themselves (fragment-shaped accesses)
 // Summation orders are those of the launches this replaces (bias first, K ascending, identity last with the same fp32 additions):
 // block output and next t1 are bit-identical to conv3x3_xres + igemm launches.
-// LDS: XB0 | XB1 (2 x 36,864: 270 padded positions x 128 B, chunk c of position q at c ^ (q & 7)); T2 (2 x 26,624) overlays them once
-// conv2 is done; OUTC (2 x 26,624) follows T2 and overlaps the end of XB1; ring 3 x 16,384; biases 3,072  = 158,720 B.
-// (C1N = 0, the stage's last block: no OUTC, and T2 sits behind XB0 so the next tile's first chunk can be fetched early.)
+// LDS, C1N = 128: XB0 | XB1 2 x 36,864 (270 padded positions x 128 B, chunk c of position q at c ^ (q & 7)); T2 2 x 26,624 at 0 and OUTC
+// 26,624 at 53,248 overlay them once conv2 is done; RESB 28,672 (224 rows: 7 DMA passes); ring 3 x 16,384; biases 3,072 = 160,768 B.  The
+// next tile's XB0 can only be fetched once T2 is dead (last position), XB1 at the next tile's first position (needed nine stages later).
+// C1N = 0: no OUTC / RESB, T2 at 53,248 (behind XB0, so the next tile's first chunk is fetched two positions early) = 158,720 B.
 // ------------------------------------------------------------------------------------------------
 struct Block2Args {
     const __bf16* t1;     // (N,28,28,128)  this block's conv1 output
