@@ -1084,7 +1084,11 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                 const int rr = rem / PW, cc = rem - rr * PW;
                 const int n = n0 + panel, y = band * TR + rr - 1, x = cc - 1;
                 const bool ok = q < PPT && tile < n_tiles && n < a.N && (unsigned)y < (unsigned)IH && (unsigned)x < (unsigned)IW;
-                x_voff[i] = ok ? (unsigned)(((n * IH + y) * IW + x) * a.Cin + (slot ^ (q & 7)) * 8) * 2u : kOobOffset;
+                // 16-B chunk c of a position is stored at c ^ key, key = (panel * TR * IW + rr * IW + cc) & 7: for the 16 consecutive output pixels
+                // of an MFMA column block the positions a tap reads then have CONSECUTIVE keys also across row and image wraps (keyed on the
+                // padded position q itself, a wrap shifts the key by PW - IW = 2 and the block's reads collide: 41 % of the LDS cycles at
+                // 14x14 / 7x7 were bank conflicts)
+                x_voff[i] = ok ? (unsigned)(((n * IH + y) * IW + x) * a.Cin + (slot ^ ((panel * (TR * IW) + rr * IW + cc) & 7)) * 8) * 2u : kOobOffset;
                 if (XRES_ABL & 32) x_voff[i] = kOobOffset;
             }
         };
@@ -1182,6 +1186,7 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
         const int w_ph0 = (fq ^ (fr & 7)) << 4;                         // kk = 0; kk = 1 is ^ 64
         const int cout_lane = wave_c * MR * 16 + 8 * fq;
         // this lane's pixel of each of the wave's blocks: padded position at tap (0,0) (block 13 of the second half does not exist)
+        const int p_lane = 16 * 7 * wave_p + fr;                          // this lane's pixel of block 0 (pixel of block j: + 16 j)
         int q0[7];
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
@@ -1220,9 +1225,10 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                         const int toff = kh * PW + kw;
                         const char* wb = smem + WRING + c_buf * WSTAGE + tt * (BC * 128) + w_row;
                         // 2 x NRW slots t = NRW kk + j: one pixel fragment, MR MFMAs; the fragment of slot t + PD is read when slot t issues
+                        // chunk key of this tap: (pixel index + kh * IW + kw) & 7, the same for every block of the lane (16 j = 0 mod 8)
+                        const int sw = toff * 128 + ((fq ^ ((p_lane + kh * IW + kw) & 7)) << 4);
                         auto xread = [&](int t) {
-                            const int row = q0[t % NRW] + toff;
-                            return *reinterpret_cast<const bf16x8*>(xb + row * 128 + ((((t >= NRW ? 4 : 0) + fq) ^ (row & 7)) << 4));
+                            return *reinterpret_cast<const bf16x8*>(xb + q0[t % NRW] * 128 + (t >= NRW ? (sw ^ 64) : sw));
                         };
                         // order pinned with sched_group_barrier: hoisted by the compiler, the reads of a whole step (three taps) are live at once
                         constexpr bool W2 = (MR <= 2);                  // both K halves' weight fragments up front (registers permitting)
@@ -1317,13 +1323,11 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
             int qa[7];
 #pragma unroll
             for (int j = 0; j < 7; ++j) qa[j] = q0[j] * 128 + ((fq ^ (q0[j] & 7)) << 4);
-            auto xread = [&](const char* xb, int toff, int t) {
-                if constexpr (XRES_ABL & 16) { return __builtin_bit_cast(bf16x8, (u32x4){(unsigned)toff, 1u, 2u, (unsigned)t}); }
+            // `sw` = toff * 128 + ((fq ^ key) << 4) with the tap's chunk key (p_lane + kh * IW + kw) & 7 (see the loader)
+            auto xread = [&](const char* xb, int sw, int t) {
+                if constexpr (XRES_ABL & 16) { return __builtin_bit_cast(bf16x8, (u32x4){(unsigned)sw, 1u, 2u, (unsigned)t}); }
                 else if constexpr (XRES_ABL & 1) { return *reinterpret_cast<const bf16x8*>(xb + (qa[t % NRW] ^ (t >= NRW ? 64 : 0))); }
-                else {
-                const int row = q0[t % NRW] + toff;
-                return *reinterpret_cast<const bf16x8*>(xb + row * 128 + ((((t >= NRW ? 4 : 0) + fq) ^ (row & 7)) << 4));
-                }
+                else { return *reinterpret_cast<const bf16x8*>(xb + q0[t % NRW] * 128 + (t >= NRW ? (sw ^ 64) : sw)); }
             };
             auto wread = [&](const char* wb, int i) {                   // i < MR: K half 0 of cout block i; else K half 1 of block i - MR
                 return *reinterpret_cast<const bf16x8*>(wb + (i % MR) * 2048 + (i < MR ? w_ph0 : (w_ph0 ^ 64)));
@@ -1370,17 +1374,17 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < 2 * MR; ++i) wA[i] = wread(wb, i);
 #pragma unroll
-                for (int t = 0; t < PD; ++t) xA[t] = xread(smem, 0, t);
+                for (int t = 0; t < PD; ++t) xA[t] = xread(smem, (fq ^ (p_lane & 7)) << 4, t);
             }
             init_acc(tile);
             auto step = [&](bf16x8 (&wc)[2 * MR], bf16x8 (&xc)[PD], bf16x8 (&wn)[2 * MR], bf16x8 (&xn)[PD]) {
                 const int kh = (s >= 6) ? 2 : (s >= 3) ? 1 : 0, kw = s - 3 * kh;
-                const int toff = kh * PW + kw;
+                const int toff = (kh * PW + kw) * 128 + ((fq ^ ((p_lane + kh * IW + kw) & 7)) << 4);     // (with the tap's chunk key)
                 const char* xb = smem + x_par * XBUF;
                 int ns = s + 1, nx_par = x_par;
                 if (ns == SPC) { ns = 0; nx_par ^= 1; }
                 const int nkh = (ns >= 6) ? 2 : (ns >= 3) ? 1 : 0, nkw = ns - 3 * nkh;
-                const int ntoff = nkh * PW + nkw;
+                const int ntoff = (nkh * PW + nkw) * 128 + ((fq ^ ((p_lane + nkh * IW + nkw) & 7)) << 4);
                 const int nc_buf = (c_buf == NSTAGE - 1) ? 0 : c_buf + 1;
                 const char* nxb = smem + nx_par * XBUF;
                 const char* nwb = smem + WRING + nc_buf * WSTAGE + w_row;
@@ -2304,7 +2308,9 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
                 const int rr = q / PW, cc = q - rr * PW;
                 const int y = band * TR + rr - 1, x = cc - 1;
                 const bool ok = q < PP && tile < a.n_tiles && (unsigned)y < 28u && (unsigned)x < 28u;
-                x_voff[i] = (ok && !(B2_ABL & 4)) ? (unsigned)(((n * 28 + y) * 28 + x) * 128 + (slot ^ (q & 7)) * 8) * 2u : kOobOffset;
+                // chunk key of a position = (rr * IW + cc) & 7, so that a tap's reads of 16 consecutive pixels have consecutive keys across row wraps
+                // (conv3x3_xres_kernel: keyed on q, 23-41 % of the LDS cycles were bank conflicts)
+                x_voff[i] = (ok && !(B2_ABL & 4)) ? (unsigned)(((n * 28 + y) * 28 + x) * 128 + (slot ^ ((rr * IW + cc) & 7)) * 8) * 2u : kOobOffset;
             }
         };
         auto issue_band = [&](int c2) {           // 9 DMAs per wave: chunk c2 of the band decoded last
@@ -2515,10 +2521,9 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
 #pragma unroll 1
                         for (int tap = 0; tap < 9; ++tap) {
                             const int kh = (tap >= 6) ? 2 : (tap >= 3) ? 1 : 0, kw = tap - 3 * kh;
-                            const int toff = kh * PW + kw;
+                            const int sw = (kh * PW + kw) * 128 + ((fq ^ ((p0 + kh * IW + kw) & 7)) << 4);      // tap offset + the tap's chunk key
                             gemm64(NRWc, smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) {
-                                const int row = q0[t % NRW] + toff;
-                                return xb + row * 128 + ((((t >= NRW ? 4 : 0) + fq) ^ (row & 7)) << 4);
+                                return xb + q0[t % NRW] * 128 + (t >= NRW ? (sw ^ 64) : sw);
                             }, acc);
                             stage_done();
                         }
@@ -2720,7 +2725,7 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
                 const int rr = q / PW, cc = q - rr * PW;
                 const int y = tr * TR + rr - 1, x = cc - 1;
                 const bool ok = q < PP && tile < a.n_tiles && (unsigned)y < 56u && (unsigned)x < 56u;
-                x_voff[i] = ok ? (unsigned)(((n * 56 + y) * 56 + x) * 64 + (slot ^ (q & 7)) * 8) * 2u : kOobOffset;
+                x_voff[i] = ok ? (unsigned)(((n * 56 + y) * 56 + x) * 64 + (slot ^ ((rr * IW + cc) & 7)) * 8) * 2u : kOobOffset;      // (chunk key: see bneck_block2_kernel)
             }
         };
         auto issue_band = [&](int i0, int i1) {   // passes [i0, i1) of the band decoded last
@@ -2885,10 +2890,9 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
 #pragma unroll 1
                     for (int tap = 0; tap < 9; ++tap) {
                         const int kh = (tap >= 6) ? 2 : (tap >= 3) ? 1 : 0, kw = tap - 3 * kh;
-                        const int toff = kh * PW + kw;
+                        const int sw = (kh * PW + kw) * 128 + ((fq ^ ((p0 + kh * IW + kw) & 7)) << 4);      // tap offset + the tap's chunk key
                         gemm64(smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) {
-                            const int row = q0[t % NQ] + toff;
-                            return smem + XB_OFF + row * 128 + ((((t >= NQ ? 4 : 0) + fq) ^ (row & 7)) << 4);
+                            return smem + XB_OFF + q0[t % NQ] * 128 + (t >= NQ ? (sw ^ 64) : sw);
                         }, acc);
                         stage_done();
                     }
