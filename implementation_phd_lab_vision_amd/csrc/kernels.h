@@ -3970,8 +3970,13 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused2_kernel(const TIN* __re
     const int fr = lane & 15, fq = lane >> 4;
     const int rr = wave >> 1, ch = wave & 1;           // conv row of the round, channel half (couts 32*ch .. 32*ch+31)
 
-    for (int c = tid; c < STEM_W_BYTES / 16; c += SF_THREADS)
-        *reinterpret_cast<u32x4*>(s_w + c * 16) = *reinterpret_cast<const u32x4*>(wpk + c * 16);
+    // weight rows are 64 B (32 K values): chunk q of row r of a 16-row fragment block is stored at q ^ {0,2,3,1}[(r >> 2) & 3], which spreads
+    // the 16 lanes of every ds_read_b128 group over the 16 (bank quadrant, chunk) pairs -- stored linearly, rows r and r + 12 (same
+    // quadrant, same chunk) made every weight-fragment read a 2-way conflict: 26 % of this kernel's LDS cycles
+    for (int c = tid; c < STEM_W_BYTES / 16; c += SF_THREADS) {
+        const int row = c >> 2, q = c & 3, key = (0x78 >> (((row >> 2) & 3) * 2)) & 3;       // {0,2,3,1} packed two bits each = 0b01'11'10'00
+        *reinterpret_cast<u32x4*>(s_w + (row * 4 + (q ^ key)) * 16) = *reinterpret_cast<const u32x4*>(wpk + c * 16);
+    }
     if constexpr (U8) {
         for (int c = tid; c < 3 * 256; c += SF_THREADS) s_tab[c] = u8_table[c];
     }
@@ -4021,7 +4026,7 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused2_kernel(const TIN* __re
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int j = 0; j < 7; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int w_frag = fr * 64 + fq * 16;
+        const int w_frag = fr * 64 + ((fq ^ ((0x78 >> (((fr >> 2) & 3) * 2)) & 3)) << 4);
         const int x_lane = fr * 16 + fq * 16;
 #pragma unroll
         for (int kh = 0; kh < 7; ++kh) {
