@@ -42,6 +42,12 @@ __device__ __forceinline__ f32x4 mfma_e(bf16x8 a, bf16x8 b, f32x4 c) {
     if constexpr (ET == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int ET>
+__device__ __forceinline__ f32x16 mfma32_e(bf16x8 a, bf16x8 b, f32x16 c) {       // v_mfma_f32_32x32x16_{bf16,f16}: 32 cycles, 8 of them on the issue port
+    if constexpr (ET == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 // ET 2 = fp8 (OCP e4m3), igemm_ws_kernel only (BASELINE configs[4]).  One byte per element: a 128-byte LDS row holds 128 values of K
 // instead of 64, everything the loaders do is unchanged (the host describes the tensors in 2-byte units), and the two 16-byte
 // fragments a lane reads per row-step are together the 32-byte operand of ONE v_mfma_scale_f32_16x16x128_f8f6f4 (K = 128; both
@@ -1024,13 +1030,33 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
 #ifndef XRES_ABL
 #define XRES_ABL 0
 #endif
-template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST, int SCHED = 0>
-__global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
+#ifndef XRES_PD           // row-block schedule: pixel fragments read ahead of their MFMAs
+#define XRES_PD 3
+#endif
+// RB = 1 ("row blocks", 14x14 and 28x28 only): the padded row is 16 / 32 positions wide and an MFMA column block is 16 consecutive POSITIONS
+// (one 14-pixel image row + 2 unused slots, or half of a 28-pixel row), 14 blocks per tile, 7 per pixel half.  A fragment address is then
+// (lane constant of the tap column and K half) + (block + kernel row) * 2048 + buffer: the K loop carries NO vector-ALU address arithmetic
+// (SCHED 0 spends ~0.85 VALU per MFMA on it; every one of those holds the SIMD's issue port for 4 of an MFMA's 16 cycles), every
+// ds_read is base + immediate, and both pixel halves have 7 blocks (the 13-block split's critical wave has 7 too).  Block b's accumulators
+// are those of the same output pixels as before with the same K order: bit-identical results.
+// RB = 3: row blocks on v_mfma_f32_32x32x16: an MFMA column block is 32 consecutive positions (7 per tile) and FOUR consumer waves -- one per SIMD,
+// 256 registers each -- own 32 couts x all 224 slots (7 accumulators of 16 registers); 4 loader waves as before.  Per K-step a wave issues
+// 28 MFMAs of 32 cycles (the 16x16x32 form: 28 of 16 cycles on each of two waves) and 32 fragment reads: the MFMA holds the issue port for 8
+// of its 32 cycles, so the other instructions of the step have 24 x 28 cycles instead of 8 x 56 to go out in.  W rows and input positions are
+// chunk-swizzled with key (row >> 1) & 7 (32 consecutive rows per ds_read_b128 instead of 16: (parity, chunk) pairs of a lane group stay
+// distinct); the W row order inside a 32-row block puts 16 CONSECUTIVE couts into a lane's 16 accumulator registers (two 16-B stores).
+// The 32-wide MFMA adds its products in another order than the 16-wide one: results differ from RB 0-2 in the last fp32 bits, so a shape that
+// takes this form takes it at every batch size.
+template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST, int SCHED = 0, int RB = 0>
+__global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int PW = IW + 2, PP = (TR + 2) * PW, PPT = NI * PP;     // padded positions per panel / per tile
+    static_assert(RB == 0 || (NI == 1 && (IW == 14 || IW == 28) && TR * (IW == 14 ? 16 : 32) == 224 && TPS == 1 && NST == 3 && SCHED == 0), "row blocks: 14 blocks of 16 positions");
+    static_assert(RB != 3 || BC == 128, "32-wide blocks: four consumer waves of 32 couts");
+    constexpr int NCW = RB == 3 ? 4 : 8;                              // consumer waves
+    constexpr int PW = RB ? (IW == 14 ? 16 : 32) : IW + 2, PP = (TR + 2) * PW, PPT = NI * PP;     // padded positions per panel / per tile
     constexpr int XPASS = (PPT + 31) / 32, XBUF = XPASS * 32 * 128;
-    constexpr int NPX = NI * TR * IW, NBLK = (NPX + 15) / 16;         // 196 pixels, 13 blocks
-    static_assert(NBLK == 13, "tiles are 196 pixels");
+    constexpr int NPX = NI * TR * IW, NBLK = RB ? 14 : (NPX + 15) / 16;         // 196 pixels, 13 blocks (row blocks: 14)
+    static_assert(RB || NBLK == 13, "tiles are 196 pixels");
     constexpr int NB = IH / TR;                                       // row bands per image
     constexpr int MR = BC / 64;                                       // 16-row cout blocks per consumer wave (4 cout groups)
     // TPS taps per K-step: 1 (ring of 3 stages, 2 in flight) or 3 = a whole kernel row (ring of 2 long stages, 1 in flight): a step has a
@@ -1055,10 +1081,10 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
     const int spt = SPC * cch;                                        // steps per tile
     const int total = my_tiles * spt;
 
-    if (wave >= 8) {
+    if (wave >= NCW) {
         // =============================== loader waves ===============================================
-        const int lw = wave - 8;
-        const int lt = tid - 512;
+        const int lw = wave - NCW;
+        const int lt = tid - NCW * 64;
         const int srow = lt >> 3, slot = lt & 7;
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w), 0, a.w_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, (unsigned)a.M * (unsigned)(a.Cin * 2), 0x00020000);
@@ -1069,8 +1095,12 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
             for (int i = 0; i < WPASS; ++i) {
                 const int row = i * 32 + srow;                           // stage row: tap row / BC of the step, channel row % BC
                 const int tt = row / BC, rho = row - tt * BC;
-                const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
-                w_voff[i] = (unsigned)((c0 + cl) * a.Ktot + tt * a.Cin + (slot ^ (rho & 7)) * 8) * 2u;
+                // cout of LDS row rho.  16-wide MFMA: lane (fq) of block pair (2t, 2t+1) ends up with channels 32t + 8 fq .. + 7.  32-wide: register r of
+                // lane half h is row (r & 3) + 8 (r >> 2) + 4 h of the block, and holds cout 16 h + r
+                const int cl = RB == 3 ? ((rho & ~31) | (rho & 3) | (((rho >> 3) & 3) << 2) | (((rho >> 2) & 1) << 4))
+                                       : ((rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3));
+                const int wkey = RB == 3 ? ((rho >> 1) & 7) : (rho & 7);
+                w_voff[i] = (unsigned)((c0 + cl) * a.Ktot + tt * a.Cin + (slot ^ wkey) * 8) * 2u;
                 if (XRES_ABL & 32) w_voff[i] = kOobOffset;
             }
         };
@@ -1088,7 +1118,9 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                 // of an MFMA column block the positions a tap reads then have CONSECUTIVE keys also across row and image wraps (keyed on the
                 // padded position q itself, a wrap shifts the key by PW - IW = 2 and the block's reads collide: 41 % of the LDS cycles at
                 // 14x14 / 7x7 were bank conflicts)
-                x_voff[i] = ok ? (unsigned)(((n * IH + y) * IW + x) * a.Cin + (slot ^ ((panel * (TR * IW) + rr * IW + cc) & 7)) * 8) * 2u : kOobOffset;
+                // (row blocks: PW = 0 mod 8, so the key of a position is its column's, cc & 7, whatever block and kernel row it is read for)
+                const int key = RB == 3 ? ((cc >> 1) & 7) : RB ? (cc & 7) : ((panel * (TR * IW) + rr * IW + cc) & 7);
+                x_voff[i] = ok ? (unsigned)(((n * IH + y) * IW + x) * a.Cin + (slot ^ key) * 8) * 2u : kOobOffset;
                 if (XRES_ABL & 32) x_voff[i] = kOobOffset;
             }
         };
@@ -1108,7 +1140,7 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
         // last step: passes go beside steps 1 and 2)
         // (SCHED 1: the consumers pass a step's barrier in the MIDDLE of that step and go on reading its input fragments, so the refill
         // of the other buffer starts one step later)
-        constexpr int XS0 = D + (SCHED ? 1 : 0), XPS = (XPASS + (SPC - XS0) - 1) / (SPC - XS0);     // first step that carries passes, passes per step
+        constexpr int XS0 = D + ((SCHED || RB == 2) ? 1 : 0), XPS = (XPASS + (SPC - XS0) - 1) / (SPC - XS0);     // first step that carries passes, passes per step
         auto xp_lo = [&](int s) { return s < XS0 ? XPASS : (XPS * (s - XS0) < XPASS ? XPS * (s - XS0) : XPASS); };
         auto xp_hi = [&](int s) { return s < XS0 ? XPASS : (XPS * (s - XS0 + 1) < XPASS ? XPS * (s - XS0 + 1) : XPASS); };
         static_assert(XPS * (SPC - XS0) >= XPASS, "the chunk's steps carry all input passes");
@@ -1177,6 +1209,87 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
             R50_MARK(2)                           // barrier
         }
         R50_STAMP_FLUSH(12)
+    } else if constexpr (RB == 3) {
+        // =============================== consumer waves, 32-wide blocks ==============================
+        constexpr int NBK = 7, NS = 4 * NBK, PD = XRES_PD + 1;            // 7 blocks of 32 slots; slot t = 7 ks + b of a step; fragments read ahead
+        const int lr = lane & 31, lh = lane >> 5;
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+        int vb[3][4];                                                   // [tap column][K sub-step]: position lr + kw, chunk (2 ks + lh) ^ key
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) vb[kw][ks] = (lr + kw) * 128 + (((2 * ks + lh) ^ (((lr + kw) >> 1) & 7)) << 4);
+        int wv[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wv[ks] = WRING + (wave * 32 + lr) * 128 + (((2 * ks + lh) ^ ((lr >> 1) & 7)) << 4);
+        const int cout_lane = wave * 32 + 16 * lh;                      // this lane's 16 consecutive couts
+        f32x16 acc[NBK];
+        int x_par = 0;
+        __builtin_amdgcn_s_barrier();             // step 0 and the first input chunk landed
+        for (int tile = first; tile < n_tiles; tile += grid) {
+            const int c0 = (tile % nct) * BC;
+            {
+                f32x16 bv;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 4 * q);
+                    bv[4 * q] = t4[0]; bv[4 * q + 1] = t4[1]; bv[4 * q + 2] = t4[2]; bv[4 * q + 3] = t4[3];
+                }
+#pragma unroll
+                for (int b = 0; b < NBK; ++b) acc[b] = bv;
+            }
+            for (int c = 0; c < cch; ++c) {
+                const char* const xc = smem + x_par * XBUF;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int kh = tap / 3, kw = tap - 3 * kh;
+                    const char* const xk = xc + kh * 2048 * (PW / 16);
+                    const char* const wk = smem + (tap % 3) * WSTAGE;
+                    auto xread = [&](int t) { return *reinterpret_cast<const bf16x8*>(xk + vb[kw][t / NBK] + (t % NBK) * 4096); };
+                    bf16x8 x[NS], wf[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(wk + wv[ks]);
+#pragma unroll
+                    for (int t = 0; t < PD; ++t) x[t] = xread(t);
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) {
+                        acc[t % NBK] = mfma32_e<ET>(wf[t / NBK], x[t], acc[t % NBK]);
+                        if (t + PD < NS) x[t + PD] = xread(t + PD);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4 + PD, 0);
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (t + PD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                  // the barrier stays behind the step's last fragment read
+                    __builtin_amdgcn_s_barrier();
+                }
+                x_par ^= 1;
+            }
+            // ---- epilogue: ReLU, 16-bit, two 16-B stores per valid slot (slot = 32 b + lr = padded row * PW + column)
+            const int pt = tile / nct;
+            const int band = pt % NB, n = pt / NB;
+#pragma unroll
+            for (int b = 0; b < NBK; ++b) {
+                const int sl = 32 * b + lr;
+                const int r = sl / PW, cx = sl - r * PW;
+                const bool ok = cx < IW && n < a.N;
+                const unsigned pix = (unsigned)((n * IH + band * TR + r) * IW + cx);
+                const unsigned voff = ok ? (pix * (unsigned)a.Cout + (unsigned)(c0 + cout_lane)) * 2u : kOobOffset;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const f32x16 v = acc[b];
+                    u32x4 o = (u32x4){pack2_e<ET>(v[8 * hf], v[8 * hf + 1]), pack2_e<ET>(v[8 * hf + 2], v[8 * hf + 3]),
+                                      pack2_e<ET>(v[8 * hf + 4], v[8 * hf + 5]), pack2_e<ET>(v[8 * hf + 6], v[8 * hf + 7])};
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, ok ? voff + 16u * hf : kOobOffset, 0, 0);
+                }
+            }
+        }
     } else {
         // =============================== consumer waves =============================================
         const int wave_c = wave & 3, wave_p = wave >> 2;
@@ -1443,9 +1556,221 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                 if (g + 1 < total) step(wB, xB, wA, xA);
             }
         };
+        // RB: see the kernel's head.  Ring slot of tap s is s % 3 (nine steps per chunk, three stages), so with the nine taps unrolled every LDS
+        // address of the K loop is a lane constant + an immediate.
+        auto run_steps_rb = [&]() {
+            constexpr int NRW = 7, PD = XRES_PD;
+            constexpr bool W2 = (MR <= 2);
+            const char* const xl = smem + 7 * 2048 * wave_p;           // this pixel half's first block
+            int vb[3][2];                                               // [tap column][K half]: position fr + kw, chunk (fq + 4 kk) ^ key
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) vb[kw][kk] = (fr + kw) * 128 + (((fq + 4 * kk) ^ ((fr + kw) & 7)) << 4);
+            const char* const wl0 = smem + WRING + w_row + w_ph0;
+            const char* const wl1 = smem + WRING + w_row + (w_ph0 ^ 64);
+            int x_par = 0;
+            for (int tile = first; tile < n_tiles; tile += grid) {
+                const int c0 = (tile % nct) * BC;
+#pragma unroll
+                for (int t = 0; t < MR / 2; ++t) {
+                    const f32x4 b_lo = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t);
+                    const f32x4 b_hi = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t + 4);
+#pragma unroll
+                    for (int j = 0; j < NRW; ++j) { acc[2 * t][j] = b_lo; acc[2 * t + 1][j] = b_hi; }
+                }
+                for (int c = 0; c < cch; ++c) {
+                    const char* const xc = xl + x_par * XBUF;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int kh = tap / 3, kw = tap - 3 * kh;
+                        const char* const x0 = xc + vb[kw][0] + kh * 2048 * (PW / 16);
+                        const char* const x1 = xc + vb[kw][1] + kh * 2048 * (PW / 16);
+                        const char* const w0 = wl0 + (tap % 3) * WSTAGE;
+                        const char* const w1 = wl1 + (tap % 3) * WSTAGE;
+                        auto xread = [&](int t) { return *reinterpret_cast<const bf16x8*>((t >= NRW ? x1 : x0) + (t % NRW) * 2048); };
+                        bf16x8 x[2 * NRW], wf[MR], wg[W2 ? MR : 1];
+#pragma unroll
+                        for (int m = 0; m < MR; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(w0 + m * 2048);
+                        if constexpr (W2) {
+#pragma unroll
+                            for (int m = 0; m < MR; ++m) wg[m] = *reinterpret_cast<const bf16x8*>(w1 + m * 2048);
+                        }
+#pragma unroll
+                        for (int t = 0; t < PD; ++t) x[t] = xread(t);
+#pragma unroll
+                        for (int t = 0; t < 2 * NRW; ++t) {
+                            if constexpr (!W2) {
+                                if (t == NRW) {
+#pragma unroll
+                                    for (int m = 0; m < MR; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(w1 + m * 2048);
+                                }
+                            }
+#pragma unroll
+                            for (int m = 0; m < MR; ++m) acc[m][t % NRW] = mfma_e<ET>((W2 && t >= NRW) ? wg[m] : wf[m], x[t], acc[m][t % NRW]);
+                            if (t + PD < 2 * NRW) x[t + PD] = xread(t + PD);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x100, (W2 ? 2 * MR : MR) + PD, 0);
+#pragma unroll
+                        for (int t = 0; t < 2 * NRW; ++t) {
+                            if (!W2 && t == NRW) __builtin_amdgcn_sched_group_barrier(0x100, MR, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);
+                            if (t + PD < 2 * NRW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);              // the barrier stays behind the step's last fragment read
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    x_par ^= 1;
+                }
+                // ---- epilogue: ReLU, 16-bit, one 16-B store per valid slot and block pair (slot = 16 b + fr = padded row * PW + column)
+                const int pt = tile / nct;
+                const int band = pt % NB, n = pt / NB;
+#pragma unroll
+                for (int j = 0; j < NRW; ++j) {
+                    const int sl = 16 * (7 * wave_p + j) + fr;
+                    const int r = sl / PW, cx = sl - r * PW;
+                    const bool ok = cx < IW && n < a.N;
+                    const unsigned pix = (unsigned)((n * IH + band * TR + r) * IW + cx);
+#pragma unroll
+                    for (int t = 0; t < MR / 2; ++t) {
+                        const f32x4 lo = acc[2 * t][j], hi = acc[2 * t + 1][j];
+                        u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+                        if (a.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                        }
+                        const unsigned voff = ok ? (pix * (unsigned)a.Cout + (unsigned)(c0 + cout_lane + 32 * t)) * 2u : kOobOffset;
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff, 0, 0);
+                    }
+                }
+            }
+        };
+        // RB 2: row blocks + the barrier in the MIDDLE of the step (SCHED 1's idea with static addresses): behind the barrier of step g -- which
+        // says that stage g + 1 has landed -- every remaining slot of step g carries one read of step g + 1's operands (4 weight fragments, the
+        // first PD pixel fragments), so a step opens with its operands in registers instead of with eight waves bursting 7 reads each into the
+        // LDS and every SIMD idling for that loaded round trip.  Hazards as SCHED 1 (weights of step g are in registers when its barrier is
+        // passed; the loaders refill an input buffer one step later, XS0).  Same MFMA order per accumulator: bit-identical results.
+        auto run_steps_rbm = [&](auto) {
+            constexpr int NRW = 7, NS = 2 * NRW, PD = 3, NXT = 2 * MR + PD, TB = NS - NXT;
+            static_assert(MR == 2 && TB >= 1, "mid-step barrier: 128 couts per tile");
+            const char* const xl = smem + 7 * 2048 * wave_p;
+            int vb[3][2];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) vb[kw][kk] = (fr + kw) * 128 + (((fq + 4 * kk) ^ ((fr + kw) & 7)) << 4);
+            const char* const wl0 = smem + WRING + w_row + w_ph0;
+            const char* const wl1 = smem + WRING + w_row + (w_ph0 ^ 64);
+            int x_par = 0;
+            bf16x8 wc[2 * MR], xc[PD];
+            // operands of step 0 (stage 0 and the first input chunk landed: the barrier in front of this call)
+#pragma unroll
+            for (int i = 0; i < 2 * MR; ++i) wc[i] = *reinterpret_cast<const bf16x8*>((i < MR ? wl0 : wl1) + (i % MR) * 2048);
+#pragma unroll
+            for (int t = 0; t < PD; ++t) xc[t] = *reinterpret_cast<const bf16x8*>(xl + vb[0][0] + t * 2048);
+            for (int tile = first; tile < n_tiles; tile += grid) {
+                const int c0 = (tile % nct) * BC;
+#pragma unroll
+                for (int t = 0; t < MR / 2; ++t) {
+                    const f32x4 b_lo = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t);
+                    const f32x4 b_hi = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t + 4);
+#pragma unroll
+                    for (int j = 0; j < NRW; ++j) { acc[2 * t][j] = b_lo; acc[2 * t + 1][j] = b_hi; }
+                }
+                for (int c = 0; c < cch; ++c) {
+                    const char* const xc0 = xl + x_par * XBUF;
+                    const char* const xn0 = xl + (x_par ^ 1) * XBUF;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int kh = tap / 3, kw = tap - 3 * kh;
+                        const int ntap = tap == 8 ? 0 : tap + 1, nkh = ntap / 3, nkw = ntap - 3 * nkh;
+                        const char* const x0 = xc0 + vb[kw][0] + kh * 2048 * (PW / 16);
+                        const char* const x1 = xc0 + vb[kw][1] + kh * 2048 * (PW / 16);
+                        const char* const nx0 = (tap == 8 ? xn0 : xc0) + vb[nkw][0] + nkh * 2048 * (PW / 16);
+                        const char* const nw0 = wl0 + (ntap % 3) * WSTAGE;
+                        const char* const nw1 = wl1 + (ntap % 3) * WSTAGE;
+                        auto xread = [&](int t) { return *reinterpret_cast<const bf16x8*>((t >= NRW ? x1 : x0) + (t % NRW) * 2048); };
+                        bf16x8 x[NS], wn[2 * MR], xn[PD];
+#pragma unroll
+                        for (int t = 0; t < PD; ++t) x[t] = xc[t];
+                        // ---- slots in front of the barrier
+#pragma unroll
+                        for (int t = 0; t < TB; ++t) {
+#pragma unroll
+                            for (int m = 0; m < MR; ++m) acc[m][t % NRW] = mfma_e<ET>(t >= NRW ? wc[MR + m] : wc[m], x[t], acc[m][t % NRW]);
+                            x[t + PD] = xread(t + PD);
+                        }
+#pragma unroll
+                        for (int t = 0; t < TB; ++t) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_barrier();                   // the NEXT step's stage has landed; nobody reads the stage before this one any more
+                        __builtin_amdgcn_sched_barrier(0);
+                        // ---- slots behind it, each with one read of the next step's operands
+#pragma unroll
+                        for (int t = TB; t < NS; ++t) {
+#pragma unroll
+                            for (int m = 0; m < MR; ++m) acc[m][t % NRW] = mfma_e<ET>(t >= NRW ? wc[MR + m] : wc[m], x[t], acc[m][t % NRW]);
+                            if (t + PD < NS) x[t + PD] = xread(t + PD);
+                            const int r = t - TB;
+                            if (r < 2 * MR) wn[r] = *reinterpret_cast<const bf16x8*>((r < MR ? nw0 : nw1) + (r % MR) * 2048);
+                            else xn[r - 2 * MR] = *reinterpret_cast<const bf16x8*>(nx0 + (r - 2 * MR) * 2048);
+                        }
+#pragma unroll
+                        for (int t = TB; t < NS; ++t) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);
+                            if (t + PD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < 2 * MR; ++i) wc[i] = wn[i];
+#pragma unroll
+                        for (int t = 0; t < PD; ++t) xc[t] = xn[t];
+                    }
+                    x_par ^= 1;
+                }
+                // ---- epilogue (as RB 1)
+                const int pt = tile / nct;
+                const int band = pt % NB, n = pt / NB;
+#pragma unroll
+                for (int j = 0; j < NRW; ++j) {
+                    const int sl = 16 * (7 * wave_p + j) + fr;
+                    const int r = sl / PW, cx = sl - r * PW;
+                    const bool ok = cx < IW && n < a.N;
+                    const unsigned pix = (unsigned)((n * IH + band * TR + r) * IW + cx);
+#pragma unroll
+                    for (int t = 0; t < MR / 2; ++t) {
+                        const f32x4 lo = acc[2 * t][j], hi = acc[2 * t + 1][j];
+                        u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+                        if (a.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                        }
+                        const unsigned voff = ok ? (pix * (unsigned)a.Cout + (unsigned)(c0 + cout_lane + 32 * t)) * 2u : kOobOffset;
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff, 0, 0);
+                    }
+                }
+            }
+        };
         __builtin_amdgcn_s_barrier();             // step 0 and the first input chunk landed
-        if constexpr (SCHED == 1) {
+        if constexpr (RB == 2) {
+            run_steps_rbm(0);
+        } else if constexpr (RB == 1) {
+            run_steps_rb();
+        } else if constexpr (SCHED == 1) {
             if (wave_p == 0) run_steps_mid(std::integral_constant<int, 7>{});
+            else run_steps_mid(std::integral_constant<int, 6>{});
+        } else if constexpr (SCHED == 2) {
+            // STAGGER: the two consumer waves of a SIMD (w and w + 4) run half a step apart.  Waves 0-3 keep the barrier at the END of a step,
+            // waves 4-7 take the mid-step schedule: they meet waves 0-3 at every barrier while they are in the MIDDLE of the same step, so
+            // one wave's fragment-read burst and barrier wait fall under its SIMD partner's MFMAs instead of beside the partner's own
+            // (MI355X_MICROARCH.md, Two waves per SIMD, item 9).  Hazards: a mid-step wave holds step g's weight fragments in registers when
+            // it passes barrier g, so stage g's ring slot is free for the loaders exactly as in SCHED 0; the input buffers follow SCHED 1's
+            // timing (XS0 above).  Same MFMA order per accumulator: bit-identical results.
+            if (wave_p == 0) run_steps(std::integral_constant<int, 7>{});
             else run_steps_mid(std::integral_constant<int, 6>{});
         } else {
             if (wave_p == 0) run_steps(std::integral_constant<int, 7>{});

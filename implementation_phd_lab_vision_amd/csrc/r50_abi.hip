@@ -411,12 +411,13 @@ bool is_xres_shape(const ConvArgs& a) {
           a.x_cstride == a.Cin && a.y_cstride == a.Cout && a.Ktot == 9 * a.Cin && a.et != 2)) return false;
     return (a.H == 14 && a.Cin == 256) || (a.H == 7 && a.Cin == 512) || (a.H == 28 && a.Cin == 128);
 }
-template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST, int SCHED = 0>
+template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST, int SCHED = 0, int RB = 0>
 hipError_t launch_conv3x3_xres_t(ConvArgs a, hipStream_t s) {
-    constexpr int PPT = NI * (TR + 2) * (IW + 2), XBUF = (PPT + 31) / 32 * 32 * 128;
+    constexpr int PW = RB ? (IW == 14 ? 16 : 32) : IW + 2;
+    constexpr int PPT = NI * (TR + 2) * PW, XBUF = (PPT + 31) / 32 * 32 * 128;
     constexpr size_t lds = 2 * (size_t)XBUF + NST * (size_t)TPS * BC * 128;
     static_assert(lds <= 163840, "LDS budget");
-    auto kern = conv3x3_xres_kernel<ET, BC, NI, TR, IW, IH, TPS, NST, SCHED>;
+    auto kern = conv3x3_xres_kernel<ET, BC, NI, TR, IW, IH, TPS, NST, SCHED, RB>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (g_num_cus == 0) {
@@ -428,7 +429,7 @@ hipError_t launch_conv3x3_xres_t(ConvArgs a, hipStream_t s) {
     a.n_ctiles = a.Cout / BC;
     a.n_blocks = ((a.N + NI - 1) / NI) * (IH / TR) * a.n_ctiles;
     const int grid = a.n_blocks < g_num_cus ? a.n_blocks : g_num_cus;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(RB == 3 ? 512 : 768), lds, s, a);
     return hipGetLastError();
 }
 int g_xres_variant = [] { const char* v = std::getenv("R50_XRES_VARIANT"); return v ? std::atoi(v) : 0; }();
@@ -438,7 +439,11 @@ hipError_t launch_conv3x3_xres(const ConvArgs& a, hipStream_t s) {
     // 14x14: 128 couts x one image x one tap per step (512 tiles = two full rounds at batch 256).  Measured in the network at batch 256
     // (bench.py, same box, two rounds each): generic tuned tile 82.2-82.5 k frames/s; this 83.1-83.2 k; 256 couts per tile (112
     // accumulator registers, spills outside the loop) 83.1-83.2 k; a whole kernel row per step (TPS = 3, ring of two 48-KB stages) 82.0 k.
-    const int var = g_xres_variant;               // A/B knob (R50_XRES_VARIANT / option "xres_variant")
+    // Round 3: the DEFAULT at 14x14 and 28x28 is the row-block form (variant 10: no address arithmetic in the K loop; bit-identical to the
+    // 13-block form, 55.0 -> 51.2 us and 60.6 -> 57.2 us at batch 256, profiles/r03_xres_variants.txt).  Variant 20 = the round-2 default.
+    int var = g_xres_variant;                     // A/B knob (R50_XRES_VARIANT / option "xres_variant")
+    if (var == 0 && (a.H == 14 || a.H == 28)) var = 10;
+    if (var == 20) var = 0;
     const bool deep = (var == 4);                  // ring of 4 weight stages (3 in flight) instead of 3
     if (var == 6) {                                // mid-step barrier schedule + deeper weight ring (5 / 4 / 5 stages: 4 / 3 / 4 in flight)
         if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 5, 1>(a, s);
@@ -449,6 +454,23 @@ hipError_t launch_conv3x3_xres(const ConvArgs& a, hipStream_t s) {
         if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 5, 0>(a, s);
         if (a.H == 7) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 4, 0>(a, s);
         return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 5, 0>(a, s);
+    }
+    if (var == 10 || var == 11) {                  // row blocks (kernels.h, RB 1): no address arithmetic in the K loop; 11 = 256 couts per tile at 14x14
+        if (a.H == 14) return var == 11 ? launch_conv3x3_xres_t<ET, 256, 1, 14, 14, 14, 1, 3, 0, 1>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 0, 1>(a, s);
+        if (a.H == 28) return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3, 0, 1>(a, s);
+    }
+    if (var == 13) {                               // row blocks on the 32x32x16 MFMA, four consumer waves (kernels.h, RB 3)
+        if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 0, 3>(a, s);
+        if (a.H == 28) return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3, 0, 3>(a, s);
+    }
+    if (var == 12) {                               // row blocks + mid-step barrier (kernels.h, RB 2)
+        if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 0, 2>(a, s);
+        if (a.H == 28) return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3, 0, 2>(a, s);
+    }
+    if (var == 8 || var == 9) {                    // staggered SIMD partners (kernels.h, SCHED 2); 9 = with the deeper ring
+        if (a.H == 14) return var == 9 ? launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 5, 2>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 2>(a, s);
+        if (a.H == 7) return var == 9 ? launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 4, 2>(a, s) : launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 3, 2>(a, s);
+        return var == 9 ? launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 5, 2>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3, 2>(a, s);
     }
     if (var == 5) {                                // mid-step barrier schedule (kernels.h, SCHED 1)
         if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 1>(a, s);

@@ -39,14 +39,17 @@ class RankContext:
 
     @property
     def distributed(self) -> bool:
-        return self.world > 1
+        """A process group exists: more than one rank, or ONE rank started by torchrun (RANK and WORLD_SIZE = 1 in the environment).
+        The one-rank group runs exactly the multi-rank code -- ``init_process_group("nccl", device_id=...)``, the asynchronous gather on
+        device tensors, the side-stream ordering behind it -- so the RCCL path executes on a one-GPU box (tests/test_cli_gpu.py)."""
+        return self.backend is not None
 
 
 def init_from_env(use_gpu: bool) -> RankContext:
     """Join the process group torchrun described (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
     backend "nccl" IS RCCL on ROCm; CPU rehearsals use gloo."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not ("RANK" in os.environ and "WORLD_SIZE" in os.environ and os.environ.get("R50_SINGLE_RANK_GROUP", "1") != "0"):
         return RankContext()
     rank = int(os.environ["RANK"])
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -177,6 +180,7 @@ class RoundExchange:
         self.recv = self.host = None
         self.pending = {}                       # round -> (slot, work)
         self.copied = [None, None]              # per device slot: event of the last D2H copy that read it
+        self.packed = [None, None]              # per device slot: event behind the packing kernels of the round that filled it
         self.error: Optional[BaseException] = None
         if ctx.is_root:
             self.recv = [torch.zeros((ctx.world, layout.total), dtype=torch.float32, device=device) for _ in range(2)] \
@@ -219,31 +223,42 @@ class RoundExchange:
         if self.cuda and self.copied[s] is not None:
             torch.cuda.current_stream(self.device).wait_event(self.copied[s])     # slot s: round q-2's D2H copy has read it
         self.layout.pack(self.send[s], feats, variants_batch, box_batch)
+        if self.cuda:                            # round q's block is complete HERE on the compute stream (not one round of kernels later)
+            self.packed[s] = torch.cuda.Event()
+            self.packed[s].record(torch.cuda.current_stream(self.device))
         work = None
-        if self.ctx.distributed:
+        if self.ctx.distributed:                 # issued behind the packing kernels (the collective orders itself after the current stream)
             work = dist.gather(self.send[s], list(self.recv[s].unbind(0)) if self.ctx.is_root else None, dst=0, async_op=True)
         self.pending[q] = (s, work)
 
     def collect(self, q: int) -> None:
+        """Stream ordering (round-2 ADVICE): the D2H copy of round q waits for round q's GATHER only -- the side stream is ordered
+        directly behind the collective (``work.wait()`` with the side stream current) or, without a process group, behind the event
+        recorded after the packing kernels -- never behind round q+1's forward pass, which the compute stream has queued meanwhile.
+        The compute stream meets these buffers again in ``post(q + 2)``, which waits for ``copied[s]`` (the copy, hence the gather,
+        of round q is done: send[s] and recv[s] are free).  A non-root rank only has send[s] to protect: it orders its compute
+        stream behind its (8 KB-per-frame) gather here."""
         self._check()
         s, work = self.pending.pop(q)
-        if work is not None:
-            work.wait()                          # GPU: orders the current stream behind the collective (no host block); gloo: blocks
         if not self.ctx.is_root:
+            if work is not None:
+                work.wait()                      # GPU: orders the current stream behind the collective (no host block); gloo: blocks
             return
         hs = self.free.get()                     # blocks only when the consumer is `host_slots` rounds behind
         ev = None
         if self.cuda:
-            cur = torch.cuda.current_stream(self.device)
-            done = torch.cuda.Event()
-            done.record(cur)                     # gather (and, world = 1, the packing kernels) of round q
             with torch.cuda.stream(self.side):
-                self.side.wait_event(done)
+                if work is not None:
+                    work.wait()                  # the SIDE stream waits for the collective; the compute stream does not
+                else:
+                    self.side.wait_event(self.packed[s])
                 self.host[hs].copy_(self.recv[s], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.side)
             self.copied[s] = ev
         else:
+            if work is not None:
+                work.wait()
             self.host[hs].copy_(self.recv[s])
         self.ready.put((q, hs, ev))
 

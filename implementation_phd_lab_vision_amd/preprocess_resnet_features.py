@@ -343,7 +343,8 @@ def main(argv: Optional[List[str]] = None) -> None:
     torch.cuda.set_device(device)
     log = print if ctx.is_root else (lambda *_a, **_k: None)
 
-    log(f"Device     : {device}  ({torch.cuda.get_device_name(device)}), ranks: {ctx.world}")
+    log(f"Device     : {device}  ({torch.cuda.get_device_name(device)}), ranks: {ctx.world}"
+        + (f", process group: {ctx.backend} (RCCL), one asynchronous gather per round" if ctx.distributed else ""))
     n_vars = len(AUG_NAMES) if args.augment else 1
     log(f"Augment    : {args.augment}  ({'4 variants/clip → ' + ', '.join(AUG_NAMES) if args.augment else 'none'})")
     log(f"Shard size : {args.shard_size} clips  ({args.shard_size * n_vars} variant entries/shard)")

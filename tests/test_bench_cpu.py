@@ -52,3 +52,51 @@ def test_preheat_step_count_follows_the_all_reduced_time(bench):
 
 def test_host_cores_is_positive_and_bounded(bench):
     assert 1 <= bench.host_cores() <= 64
+
+
+def _write_counter_csv(path, counter, launches):
+    """launches: (dispatch id, kernel name, grid, KiB)"""
+    import csv
+    cols = ["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "Thread_Id", "Grid_Size", "Kernel_Id", "Kernel_Name",
+            "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Counter_Name",
+            "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+    with open(path, "w", newline="") as fh:
+        w = csv.writer(fh, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(cols)
+        for did, name, grid, kib in launches:
+            w.writerow([did, did, "Agent 2", 1, 1, 1, grid, 9, name, 512, 0, 0, 8, 0, 32, counter, kib, 0, 1])
+
+
+def test_pmc_summary_counts_full_batch_launches_only(tmp_path):
+    """Round-2 bug: bench.py's batch-2 check forward was averaged into every class (stem 77.3 MB x 7 and one launch of 1.4 MB).  The
+    summary keeps only (kernel, grid) groups that occur a whole number of times per full-batch forward."""
+    sys.path.insert(0, str(ROOT / "scripts"))
+    import io
+    import pmc_bench_summary as P
+    stem, conv = "void stem_fused2_kernel<0>(float const*)", "void igemm_ws_kernel<0, 128, 224, 4, 2, 4, 3>(ConvArgs)"
+    fetch, write = [], []
+    did = 0
+    for f in range(7):                                   # 7 full-batch forwards: stem, conv, conv (two layers on one kernel, same grid)
+        for name, grid, kib_f, kib_w in ((stem, 131072, 77300.0, 200000.0), (conv, 196608, 50000.0, 25000.0), (conv, 196608, 30000.0, 25000.0)):
+            did += 1
+            fetch.append((did, name, grid, kib_f)); write.append((did, name, grid, kib_w))
+    for name, grid, kib_f, kib_w in ((stem, 1024, 1400.0, 1500.0), (conv, 3072, 400.0, 200.0), (conv, 3072, 300.0, 200.0)):   # the batch-2 check forward
+        did += 1
+        fetch.append((did, name, grid, kib_f)); write.append((did, name, grid, kib_w))
+    ff, wf = tmp_path / "f_counter_collection.csv", tmp_path / "w_counter_collection.csv"
+    _write_counter_csv(ff, "FETCH_SIZE", fetch)
+    _write_counter_csv(wf, "WRITE_SIZE", write)
+    log = io.StringIO()
+    layers = [{"name": "conv1", "bytes_per_launch": 360e6}, {"name": "layer3.0.conv2", "bytes_per_launch": 120e6}, {"name": "layer3.1.conv2", "bytes_per_launch": 90e6}]
+    res, table = P.summarize([str(ff)], [str(wf)], forwards=7, layers=layers, log=log)
+    assert "dropped 1 launch" in log.getvalue() and "dropped 2 launch" in log.getvalue()
+    assert res["conv1"]["launches_counted"] == 7 and res["igemm"]["launches_counted"] == 14
+    assert res["conv1"]["fetch_bytes_per_launch_raw"] == pytest.approx(77300.0 * 1024)
+    assert res["igemm"]["hbm_bytes_per_launch"] == pytest.approx((2 * 40000.0 + 25000.0) * 1024)
+    assert [r["layer"] for r in table] == ["conv1", "layer3.0.conv2", "layer3.1.conv2"]
+    assert table[1]["read_bytes_x2"] == pytest.approx(2 * 50000.0 * 1024) and table[2]["written_bytes"] == pytest.approx(25000.0 * 1024)
+    assert table[1]["ratio"] == pytest.approx((2 * 50000.0 + 25000.0) * 1024 / 120e6)
+    assert res["_step"]["launches"] == 3
+    # without the guard the check launches pull the averages down (what round 2 committed)
+    res0, table0 = P.summarize([str(ff)], [str(wf)], forwards=0, log=log)
+    assert res0["conv1"]["launches_counted"] == 8 and res0["conv1"]["fetch_bytes_per_launch_raw"] < 0.9 * 77300.0 * 1024 and table0 is None

@@ -174,3 +174,48 @@ def test_cli_device_producer_flag_end_to_end(tmp_path, lib_built, capsys):
     sh = torch.load(c / "shard_00000.pt", weights_only=True)
     assert sh["feats"].shape[0] == 16 and torch.isfinite(sh["feats"]).all() and [m["aug"] for m in sh["meta"][:4]] == ["orig", "cjitter", "hflip", "trev"]
     assert torch.equal(sh["feats"][3], sh["feats"][0].flip(0))          # trev = orig in reverse frame order
+
+
+def _torchrun_one_rank(argv, tmp_path, timeout=600):
+    """A FRESH child process (started before any GPU call in that child): torchrun, one rank, rendezvous on 127.0.0.1."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", PYTHONPATH=str(root) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", "--nproc-per-node=1", "--local-addr", "127.0.0.1"] + argv
+    res = subprocess.run(cmd, env=env, cwd=str(root), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    out = res.stdout.decode(errors="replace")
+    assert res.returncode == 0, f"torchrun child failed ({res.returncode}):\n{out[-4000:]}"
+    return out
+
+
+def test_cli_under_torchrun_runs_the_rccl_path_and_writes_the_same_files(tmp_path, lib_built):
+    """The multi-GPU code path on the hardware there is: the CLI as ONE rank under torchrun joins a process group with backend "nccl"
+    (= RCCL) bound to its device, every round's feature block goes through ``dist.gather(async_op=True)`` on device tensors, the side
+    stream is ordered behind the collective, the D2H copy lands in pinned memory and the packer thread writes the shards -- and the
+    output directory equals the one the same command writes without a process group."""
+    from implementation_phd_lab_vision_amd.preprocess_resnet_features import main
+    from tests.helpers import assert_same_feature_cache
+    common = ["--root", "unused", "--synthetic-clips", "9", "--seq-len", "4", "--batch-size", "2", "--num-workers", "0", "--shard-size", "4",
+              "--shuffle-pool", "5", "--shuffle-seed", "11", "--device", "cuda", "--max-batch", "16", "--synthetic-weights", "--augment"]
+    plain, grouped = tmp_path / "plain", tmp_path / "rccl"
+    out = _torchrun_one_rank(["-m", "implementation_phd_lab_vision_amd.preprocess_resnet_features"] + common + ["--out", str(grouped)], tmp_path)
+    assert "ranks: 1" in out and "process group: nccl" in out, out[-2000:]
+    main(common + ["--out", str(plain)])
+    assert_same_feature_cache(grouped, plain)
+
+
+def test_bench_under_torchrun_runs_gather_barrier_and_fence_on_rccl(tmp_path, lib_built):
+    """bench.py --gpus 1 as one torchrun rank: init_process_group("nccl", device_id=...), the per-step gather of the (256, 2048)
+    feature block, the all-reduced pre-heat / elapsed times and the barrier + synchronize fences all execute on RCCL."""
+    import json
+    out = _torchrun_one_rank(["bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--preheat", "0.2", "--no-secondary",
+                              "--no-cpu-baseline"], tmp_path)
+    line = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["value"] > 1000 and rec["checked"]["finite"] and rec["checked"]["equal_to_batch2_run"]
+    assert "RCCL gather" in rec["config"]["workload"]

@@ -44,7 +44,7 @@ def _run_world(world, out, case):
         assert p.returncode == 0, f"rank {rank} failed:\n{o[-3000:]}"
 
 
-@pytest.mark.parametrize("name,world", [("ref_plain", 2), ("ref_aug", 2), ("ref_plain", 3)])
+@pytest.mark.parametrize("name,world", [("ref_plain", 2), ("ref_aug", 2), ("ref_plain", 3), ("ref_plain", 1)])
 def test_world_size_n_equals_reference_output(tmp_path, name, world):
     _run_world(world, tmp_path / "out", CASES[name])
     assert_same_feature_cache(tmp_path / "out", GOLDEN / name)

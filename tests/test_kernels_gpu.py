@@ -114,9 +114,9 @@ def test_conv2d_matches_oracle(lib_built, case):
 @pytest.mark.parametrize("shape", [(5, 7, 512), (3, 28, 128), (3, 14, 256), (70, 14, 256), (300, 14, 256), (260, 7, 512)],
                          ids=lambda v: "n%d_%dx%d_c%d" % (v[0], v[1], v[1], v[2]))
 def test_xres_schedule_variants_bit_identical(lib_built, shape):
-    """conv3x3_xres_kernel: the mid-step-barrier schedule (next step's operands prefetched behind the barrier) and the deeper weight
-    rings are re-schedulings of the same MFMA sequence per accumulator -- the same bits as the default schedule, also with several
-    tiles per workgroup (n = 300 at 14x14: 600 tiles on 256 CUs) and with panels / cout tiles left ragged."""
+    """conv3x3_xres_kernel: the row-block form (round 3 default at 14x14 / 28x28), the mid-step-barrier schedule, the deeper weight
+    rings, the staggered schedule and the 32x32x16 form are re-schedulings of the same K order per accumulator -- the same bits as the
+    13-block schedule, also with several tiles per workgroup (n = 300 at 14x14: 600 tiles on 256 CUs) and with panels / cout tiles left ragged."""
     from implementation_phd_lab_vision_amd import ops
     from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
     n, hw, c = shape
@@ -128,7 +128,9 @@ def test_xres_schedule_variants_bit_identical(lib_built, shape):
     bb = ResNet50Backbone(seed=0, max_batch=2).to(d)       # only to reach the process-wide option
     try:
         ref = None
-        for var in (0, 5, 6, 7, 0):
+        # 0 = default (row blocks at 14x14 / 28x28), 20 = the 13-block form, 5-7 mid-step barrier / deeper rings, 8 staggered SIMD partners,
+        # 12 row blocks + mid-step barrier, 13 row blocks on the 32x32x16 MFMA with four consumer waves
+        for var in (20, 0, 5, 6, 7, 8, 10, 12, 13, 0):
             bb.set_option("xres_variant", var)
             numel = n * hw * hw * c
             buf = torch.full((numel + 512 * c,), -7.0, dtype=torch.bfloat16, device=d)
