@@ -1852,10 +1852,15 @@ int r50_op_bneck_tail(const void* y2, int64_t m, int cmid, const void* w3, const
     else if (cmid == 128 && c1 == 128 && !wd && !bd) e = launch_bneck_tail2(y2, m, w3, b3, res, out, w1, b1, y1n, (hipStream_t)stream);
     else if (cmid == 256 && c1 == 256 && !wd && !bd) {
         const char* v = std::getenv("R50_TAIL3_BP");          // test / A-B knob of this debug hook: real pixels per tile (1..112); unset = automatic
-        static void* wp_scratch = nullptr;                     // the hook takes plain weight matrices: packed here, per call, on the caller's stream
-        if (!wp_scratch && hipMalloc(&wp_scratch, kTail3PackedBytes) != hipSuccess) return fail(nullptr, R50_ERR_HIP, "r50_op_bneck_tail: hipMalloc");
+        // the hook takes plain weight matrices: packed here, per call, into a buffer allocated AND freed in the caller's stream order on the
+        // caller's current device (a process-wide scratch buffer would be shared by callers on other streams / devices: round-2 ADVICE)
+        void* wp_scratch = nullptr;
+        if (hipMallocAsync(&wp_scratch, kTail3PackedBytes, (hipStream_t)stream) != hipSuccess || !wp_scratch)
+            return fail(nullptr, R50_ERR_HIP, "r50_op_bneck_tail: hipMallocAsync");
         e = pack_tail3_weights(w3, w1, wp_scratch, (hipStream_t)stream);
         if (e == hipSuccess) e = launch_bneck_tail3(y2, m, wp_scratch, b3, res, out, b1, y1n, (hipStream_t)stream, 0, v ? std::atoi(v) : 0);
+        const hipError_t ef = hipFreeAsync(wp_scratch, (hipStream_t)stream);
+        if (e == hipSuccess) e = ef;
     }
     else e = hipErrorInvalidValue;
     if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,

@@ -154,13 +154,28 @@ def _calibrate_fp8(backbone, ds, args, device, log) -> None:
     else:
         n_clips = min(len(ds), args.batch_size)
         videos = []
-        for i in range(n_clips):
-            item = ds[i]
-            videos.append((item[0][0] if args.augment else item[0]))            # the orig variant's (T,3,224,224) frames
+        if args.device_producer:
+            # the frames the run itself will feed the backbone: decoded clip -> box region -> crop + resize ON THE DEVICE (the producer's
+            # kernel and resize mode), then the loader's /255 + Normalize (src/dataset.py:242-245,429).  ds[i] would go through the HOST
+            # producer (other resize arithmetic; with --synthetic-decoded --augment it needs a host ColorJitter that is not there)
+            from . import frames as F
+            from .producer import DecodedClips
+            dc = DecodedClips(ds, augment=False)
+            mode = F.RESIZE_FIXED if args.resize_mode == "fixed" else F.RESIZE_FLOAT
+            mean = torch.tensor([0.485, 0.456, 0.406], device=device).view(1, 3, 1, 1)
+            std = torch.tensor([0.229, 0.224, 0.225], device=device).view(1, 3, 1, 1)
+            for i in range(n_clips):
+                reg = dc[i]["region"].to(device)
+                u8 = F.crop_and_resize_video_uint8(reg, [0, 0, int(reg.shape[1]), int(reg.shape[2])], 224, mode)
+                videos.append((u8.to(torch.float32) / 255.0 - mean) / std)
+        else:
+            for i in range(n_clips):
+                item = ds[i]
+                videos.append((item[0][0] if args.augment else item[0]))        # the orig variant's (T,3,224,224) frames
         frames = torch.cat(videos)[: args.max_batch].to(device=device, dtype=torch.float32)
         backbone.calibrate_fp8(frames=frames)
-        log(f"fp8 scales : calibrated on the first {n_clips} clip(s) = {frames.shape[0]} real frames (margin x1.25 over their largest "
-            f"activation per tensor)")
+        log(f"fp8 scales : calibrated on the first {n_clips} clip(s) = {frames.shape[0]} real frames"
+            + (" made by the device producer" if args.device_producer else "") + " (margin x1.25 over their largest activation per tensor)")
     sc = backbone.fp8_scales
     log(f"fp8 scales : 43 tensors, representable range 448 x scale from {448 * min(sc):.3g} to {448 * max(sc):.3g}")
 
@@ -215,7 +230,8 @@ def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.Ran
     needs, :98,300,345).  The loop body is: forward passes of round q -> ``post`` (pack + async gather) -> ``collect`` round q-1
     (async D2H into a pinned slot, hand-over to the packing thread).  Nothing in it waits for the device, for a copy or for the
     packer, so round q+1's kernels are queued while round q's features travel and round q-1's clips are packed.
-    ``stats`` (optional dict) receives ``compute_done_s`` / ``total_s`` (seconds since the loop started).
+    ``stats`` (optional dict) receives ``compute_done_s`` / ``total_s`` (seconds since the loop started) and
+    ``clips_packed_at_compute_done`` (clips the packing thread had consumed when the last round was collected).
     ``producer`` (``producer.DeviceProducer``): the loader then yields DECODED clips and crop / resize / variants / features all
     happen on the device (``--device-producer``)."""
     ctx = ctx or D.RankContext()
@@ -314,6 +330,7 @@ def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.Ran
         exchange.collect(n_rounds - 1)
     if stats is not None:
         stats["compute_done_s"] = time.time() - t_all
+        stats["clips_packed_at_compute_done"] = progress["done"]      # how far the packing thread was when the last round was collected
     exchange.finish()
     if stats is not None:
         stats["total_s"] = time.time() - t_all

@@ -35,11 +35,17 @@ def decoded_item_from_reference_dataset(ds, idx: int) -> dict:
     ``_read_video_uint8_clip_fast``, ``frame_skip``, ``crop_scale``)."""
     ci = ds.index[idx]
     frames_u8 = ds._read_video_uint8_clip_fast(ci.video_path, ci.start, ci.end)          # (T,H,W,3) uint8
+    if frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:                                  # the reference's `assert C == 3` (:375-376)
+        raise AssertionError(f"decoded clip of {ci.video_path} is {tuple(frames_u8.shape)}, expected (T,H,W,3)")
     joints3d_all, joints2d_all = ds._gt_cache[ci.gt_path]
     orig_idx = torch.arange(ci.start, ci.end, dtype=torch.long) * ds.frame_skip
     if int(orig_idx[-1]) >= joints3d_all.shape[0]:
         raise RuntimeError(f"Joint index out of range for {ci.gt_path}: max orig_idx={int(orig_idx[-1])}, n_frames={joints3d_all.shape[0]}")
-    return {"frames": frames_u8, "joints3d": joints3d_all[orig_idx], "joints2d": joints2d_all[orig_idx], "cam": ci.cam_params,
+    joints3d, joints2d = joints3d_all[orig_idx], joints2d_all[orig_idx]
+    # the reference's frame-count assert (:390-392): a reader that returned fewer frames than the clip has annotations for must not
+    # silently pair frame t with the joints of another frame
+    assert frames_u8.shape[0] == joints3d.shape[0], f"Mismatch T: video {frames_u8.shape[0]} vs joints {joints3d.shape[0]}"
+    return {"frames": frames_u8, "joints3d": joints3d, "joints2d": joints2d, "cam": ci.cam_params,
             "crop_scale": float(getattr(ds, "crop_scale", 1.6))}
 
 

@@ -148,8 +148,12 @@ def test_compute_rounds_do_not_wait_for_a_slow_packer(tmp_path, monkeypatch):
         stats = {}
         run_extraction(ds, args, GatherBackbone(), torch.device("cpu"), log=lambda *_: None, host_slots=slots, stats=stats)
         runs[slots] = stats
+    # counters, not wall-clock ratios (round-2 ADVICE: those flake on a loaded host): when the LAST of the 8 rounds has been collected,
+    #  * with 16 host slots no round ever waited for a slot, so the packer (50 ms per clip against microseconds per compute round) has
+    #    consumed only the first few of the 16 clips -- the compute loop ran ahead of it;
+    #  * with ONE slot, collect(q) can only take the slot once round q - 1 has been packed completely: at least 7 rounds x 2 clips are done.
     free, throttled = runs[16], runs[1]
-    assert free["total_s"] > 0.75                                   # 16 clips x 50 ms of packing
-    assert free["compute_done_s"] < 0.4 * free["total_s"], free    # the 8 compute rounds did not wait for it
-    assert throttled["compute_done_s"] > 0.6 * throttled["total_s"], throttled
+    assert free["clips_packed_at_compute_done"] <= 8, free
+    assert throttled["clips_packed_at_compute_done"] >= 14, throttled
+    assert free["compute_done_s"] <= free["total_s"] and throttled["compute_done_s"] <= throttled["total_s"]
     assert_same_feature_cache(tmp_path / "slots16", tmp_path / "slots1")
