@@ -1783,6 +1783,242 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv 3x3 / STRIDE 2 / pad 1 with Cin = Cout (conv2 of layer2.0 and layer3.0: 56 -> 28 x 128 channels, 28 -> 14 x 256), INPUT-RESIDENT by
+// POLYPHASE PLANES.  Round 2 ran these two launches on the generic implicit GEMM (re-staging the pixel rows for every tap) at 571 and
+// 825 TFLOP/s with 1.2x / 2.0x their input bytes fetched: the slowest MFMA-bound launches of the network.
+// Output pixel (r, c), tap (kh, kw) reads input (2r + kh - 1, 2c + kw - 1): the parity of the input row is that of kh - 1, the parity of the
+// column that of kw - 1.  So the nine taps fall into four PHASE PLANES of the input -- rows odd / even x columns odd / even -- and on its
+// plane every tap is a STRIDE-1 access at offset (dr, dc) in {0,1}^2:
+//     OO (odd rows y = 2R - 1, odd cols x = 2i - 1):  taps (0,0) (0,2) (2,0) (2,2)  at (R, i) = (r + kh/2, c + kw/2)
+//     OE (odd rows, even cols x = 2i):                taps (0,1) (2,1)              at (r + kh/2, c)
+//     EO (even rows y = 2R, odd cols):                taps (1,0) (1,2)              at (r, c + kw/2)
+//     EE:                                             tap  (1,1)                    at (r, c)
+// One plane of one 64-channel chunk and one tile = (TR + 1) rows x PW positions x 128 B = 32 KB -- the size of the stride-1 kernel's input
+// buffer -- where the whole strided footprint of a tile would be 110-120 KB.  A K "virtual chunk" = (chunk, plane); its taps are steps with
+// the row-block addressing of conv3x3_xres_kernel (RB 1): plane row = PW (16 / 32) positions, output slot s = PW r + c reads position
+// s + dr PW + dc: lane constant + immediate, no address arithmetic in the K loop.  K order: (chunk, plane OO OE EO EE, tap, channel).
+// That is not the generic kernel's order, so these two shapes take this kernel at EVERY batch size.
+// LDS: THREE plane buffers (a plane of 1 step, EE, sits between planes of 2 and 4: with two buffers its successor could only be fetched
+// while EE itself runs, one step) + ring of 3 weight stages = 144 KB.  Loader schedule per chunk (iteration i = barrier interval; a pass
+// issued at iteration i is confirmed by the wait of iteration i + 1 and readable from step i + 2; a buffer is free for the plane three
+// planes later from the first step of the plane two planes later):
+//     plane          steps     its 8 passes are issued at iterations (of the chunk; 8 = the previous chunk's last)
+//     OE             4,5       8 (2), 0 (4), 1 (2)          window [8', 2]
+//     EO             6,7       1 (2), 2 (4), 3 (2)          window [0, 4]
+//     EE             8         4 (3), 5 (3), 6 (2)          window [4, 6]
+//     OO of c + 1    0..3      6 (4), 7 (4)                 window [6, 7]
+// 8 consumer waves (cout group w & 3, slot half w >> 2: 7 + 7 blocks) + 4 loader waves, as the stride-1 kernel.
+// ------------------------------------------------------------------------------------------------
+template <int ET, int BC, int TR, int OW, int OH>
+__global__ __launch_bounds__(768) void conv3x3_s2_kernel(const ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PW = OW == 14 ? 16 : 32;
+    static_assert((OW == 14 || OW == 28) && TR * PW == 224 && OH % TR == 0 && BC == 128, "14 blocks of 16 slots, 128 couts");
+    constexpr int IH = 2 * OH, IW = 2 * OW, NB = OH / TR;
+    constexpr int XPASS = 8, XBUF = XPASS * 32 * 128;                  // (TR + 1) * PW <= 256 positions
+    static_assert((TR + 1) * PW <= 256, "plane buffer");
+    constexpr int MR = BC / 64, WPASS = BC / 32, WSTAGE = BC * 128, NST = 3, D = 2;
+    constexpr int WRING = 3 * XBUF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grid = gridDim.x, first = blockIdx.x;
+    const int nct = a.Cout / BC;
+    const int n_tiles = a.n_blocks;                                   // pixel tiles x cout tiles (cout tile fastest)
+    const int my_tiles = (n_tiles - first + grid - 1) / grid;
+    const int cch = a.cin_chunks;
+    const int total = my_tiles * cch * 9;
+
+    if (wave >= 8) {
+        // =============================== loader waves ===============================================
+        const int lw = wave - 8, lt = tid - 512;
+        const int srow = lt >> 3, slot = lt & 7;
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w), 0, a.w_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, (unsigned)a.N * (unsigned)(IH * IW) * (unsigned)(a.Cin * 2), 0x00020000);
+        unsigned w_voff[WPASS], x_voff[4][XPASS];
+        auto decode_w = [&](int tile) {
+            const int c0 = (tile % nct) * BC;
+#pragma unroll
+            for (int i = 0; i < WPASS; ++i) {
+                const int rho = i * 32 + srow;
+                const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+                w_voff[i] = (unsigned)((c0 + cl) * a.Ktot + (slot ^ (rho & 7)) * 8) * 2u;
+            }
+        };
+        auto decode_x = [&](int tile) {           // per plane (py, px): source offset of plane position (R, i) or out of range (zero border)
+            const int pt = tile / nct;
+            const int band = pt % NB, n = pt / NB;
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const int py = ph >> 1, px = ph & 1;
+#pragma unroll
+                for (int i = 0; i < XPASS; ++i) {
+                    const int q = i * 32 + srow;
+                    const int R = q / PW, ii = q - R * PW;
+                    const int y = 2 * (band * TR + R) - 1 + py, x = 2 * ii - 1 + px;
+                    const bool ok = tile < n_tiles && n < a.N && R <= TR && (unsigned)y < (unsigned)IH && (unsigned)x < (unsigned)IW;
+                    x_voff[ph][i] = ok ? (unsigned)(((n * IH + y) * IW + x) * a.Cin + (slot ^ (ii & 7)) * 8) * 2u : kOobOffset;
+                }
+            }
+        };
+        // ---- weight stream: stage g = step (tile, chunk, s); tap of step s in plane order
+        int i_tile = first, i_c = 0, i_s = 0, i_buf = 0;
+        auto w_issue = [&]() -> int {
+            const int tap = (i_s < 4) ? ((i_s & 1) * 2 + (i_s >> 1) * 6) : (i_s < 6) ? (1 + (i_s - 4) * 6) : (i_s < 8) ? (3 + (i_s - 6) * 2) : 4;
+            const int wofs = __builtin_amdgcn_readfirstlane((tap * a.Cin + i_c * 64) * 2);
+            char* sbase = smem + WRING + i_buf * WSTAGE + lw * 1024;
+#pragma unroll
+            for (int i = 0; i < WPASS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LDS_AS void*)(sbase + i * 4096), 16, w_voff[i], wofs, 0, 0);
+            i_buf = (i_buf == NST - 1) ? 0 : i_buf + 1;
+            if (++i_s == 9) {
+                i_s = 0;
+                if (++i_c == cch) { i_c = 0; i_tile += grid; if (i_tile < n_tiles) decode_w(i_tile); }
+            }
+            return WPASS;
+        };
+        // ---- plane stream: the planes are fetched in K order; x_buf = buffer of the plane whose passes are being issued
+        int x_buf = 0;
+        auto x_pass = [&](int ph, int pass, int chunk) {        // ph, pass: compile-time after unrolling (the plane's (py, px) is in x_voff)
+            const int xofs = __builtin_amdgcn_readfirstlane(chunk * 128);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + x_buf * XBUF + pass * 4096 + lw * 1024), 16, x_voff[ph][pass], xofs, 0, 0);
+        };
+        auto next_buf = [&]() { x_buf = (x_buf == 2) ? 0 : x_buf + 1; };
+        decode_w(i_tile);
+        decode_x(first);
+        // prologue: plane OO of (first tile, chunk 0) whole, stage 0, the first two passes of plane OE, stage 1
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) x_pass(0, p, 0);
+        if (total > 0) w_issue();
+        next_buf();
+        x_pass(1, 0, 0); x_pass(1, 1, 0);
+        if (total > 1) w_issue();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPASS + 2) : "memory");       // plane OO and stage 0 landed
+        __builtin_amdgcn_s_barrier();
+        int t_cur = first, c_cur = 0;                                  // (tile, chunk) of the step the consumers run during this iteration
+        for (int g = 0; g < total; g += 9) {
+            // (tile, chunk) after this one, whose planes OO / OE are fetched from iteration 6 on
+            int t_nxt = t_cur, c_nxt = c_cur + 1;
+            if (c_nxt == cch) { c_nxt = 0; t_nxt += grid; }
+            const bool has_nxt = t_nxt < n_tiles;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                int ops = 0;
+                if (g + i + D < total) ops += w_issue();
+                // plane passes of this iteration (table in the kernel's head)
+                if (i == 0) { x_pass(1, 2, c_cur); x_pass(1, 3, c_cur); x_pass(1, 4, c_cur); x_pass(1, 5, c_cur); ops += 4; }
+                if (i == 1) { x_pass(1, 6, c_cur); x_pass(1, 7, c_cur); next_buf(); x_pass(2, 0, c_cur); x_pass(2, 1, c_cur); ops += 4; }
+                if (i == 2) { x_pass(2, 2, c_cur); x_pass(2, 3, c_cur); x_pass(2, 4, c_cur); x_pass(2, 5, c_cur); ops += 4; }
+                if (i == 3) { x_pass(2, 6, c_cur); x_pass(2, 7, c_cur); next_buf(); ops += 2; }
+                if (i == 4) { x_pass(3, 0, c_cur); x_pass(3, 1, c_cur); x_pass(3, 2, c_cur); ops += 3; }
+                if (i == 5) { x_pass(3, 3, c_cur); x_pass(3, 4, c_cur); x_pass(3, 5, c_cur); ops += 3; }
+                if (i == 6) {
+                    x_pass(3, 6, c_cur); x_pass(3, 7, c_cur); next_buf(); ops += 2;
+                    if (has_nxt) {
+                        if (t_nxt != t_cur) decode_x(t_nxt);
+                        x_pass(0, 0, c_nxt); x_pass(0, 1, c_nxt); x_pass(0, 2, c_nxt); x_pass(0, 3, c_nxt); ops += 4;
+                    }
+                }
+                if (i == 7 && has_nxt) { x_pass(0, 4, c_nxt); x_pass(0, 5, c_nxt); x_pass(0, 6, c_nxt); x_pass(0, 7, c_nxt); next_buf(); ops += 4; }
+                if (i == 8 && has_nxt) { x_pass(1, 0, c_nxt); x_pass(1, 1, c_nxt); ops += 2; }
+                wait_vmcnt(ops);                  // everything issued before this iteration has landed: step g + i + 1's stage and planes
+                __builtin_amdgcn_s_barrier();
+            }
+            t_cur = t_nxt; c_cur = c_nxt;
+        }
+    } else {
+        // =============================== consumer waves =============================================
+        constexpr int NRW = 7, PD = 3;
+        const int wave_c = wave & 3, wave_p = wave >> 2;
+        const int fr = lane & 15, fq = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+        const int w_row = (wave_c * MR * 16 + fr) * 128;
+        const int w_ph0 = (fq ^ (fr & 7)) << 4;
+        const int cout_lane = wave_c * MR * 16 + 8 * fq;
+        int vb[2][2];                                                   // [dc][K half]: position fr + dc, chunk (fq + 4 kk) ^ key
+#pragma unroll
+        for (int dc = 0; dc < 2; ++dc)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) vb[dc][kk] = (fr + dc) * 128 + (((fq + 4 * kk) ^ ((fr + dc) & 7)) << 4);
+        const char* const wl0 = smem + WRING + w_row + w_ph0;
+        const char* const wl1 = smem + WRING + w_row + (w_ph0 ^ 64);
+        f32x4 acc[MR][NRW];
+        int x_buf = 0;
+        __builtin_amdgcn_s_barrier();             // step 0: plane OO of the first chunk and stage 0 landed
+        for (int tile = first; tile < n_tiles; tile += grid) {
+            const int c0 = (tile % nct) * BC;
+#pragma unroll
+            for (int t = 0; t < MR / 2; ++t) {
+                const f32x4 b_lo = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t);
+                const f32x4 b_hi = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t + 4);
+#pragma unroll
+                for (int j = 0; j < NRW; ++j) { acc[2 * t][j] = b_lo; acc[2 * t + 1][j] = b_hi; }
+            }
+            for (int c = 0; c < cch; ++c) {
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {
+                    // step s of the chunk: plane, offset (dr, dc) on the plane (the loader's tap order)
+                    const int dr = (s < 4) ? (s >> 1) : (s < 6) ? (s - 4) : 0;
+                    const int dc = (s < 4) ? (s & 1) : (s >= 6 && s < 8) ? (s - 6) : 0;
+                    const char* const xc = smem + x_buf * XBUF + 7 * 2048 * wave_p + dr * (PW * 128);
+                    const char* const x0 = xc + vb[dc][0];
+                    const char* const x1 = xc + vb[dc][1];
+                    const char* const w0 = wl0 + (s % 3) * WSTAGE;
+                    const char* const w1 = wl1 + (s % 3) * WSTAGE;
+                    auto xread = [&](int t) { return *reinterpret_cast<const bf16x8*>((t >= NRW ? x1 : x0) + (t % NRW) * 2048); };
+                    bf16x8 x[2 * NRW], wf[MR], wg[MR];
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(w0 + m * 2048);
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) wg[m] = *reinterpret_cast<const bf16x8*>(w1 + m * 2048);
+#pragma unroll
+                    for (int t = 0; t < PD; ++t) x[t] = xread(t);
+#pragma unroll
+                    for (int t = 0; t < 2 * NRW; ++t) {
+#pragma unroll
+                        for (int m = 0; m < MR; ++m) acc[m][t % NRW] = mfma_e<ET>(t >= NRW ? wg[m] : wf[m], x[t], acc[m][t % NRW]);
+                        if (t + PD < 2 * NRW) x[t + PD] = xread(t + PD);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * MR + PD, 0);
+#pragma unroll
+                    for (int t = 0; t < 2 * NRW; ++t) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);
+                        if (t + PD < 2 * NRW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                  // the barrier stays behind the step's last fragment read
+                    __builtin_amdgcn_s_barrier();
+                    if (s == 3 || s == 5 || s == 7 || s == 8) x_buf = (x_buf == 2) ? 0 : x_buf + 1;      // the next step opens the next plane
+                }
+            }
+            // ---- epilogue: ReLU, 16-bit, one 16-B store per valid slot and block pair (slot = 16 b + fr = output row * PW + column)
+            const int pt = tile / nct;
+            const int band = pt % NB, n = pt / NB;
+#pragma unroll
+            for (int j = 0; j < NRW; ++j) {
+                const int sl = 16 * (7 * wave_p + j) + fr;
+                const int r = sl / PW, cx = sl - r * PW;
+                const bool ok = cx < OW && n < a.N;
+                const unsigned pix = (unsigned)((n * OH + band * TR + r) * OW + cx);
+#pragma unroll
+                for (int t = 0; t < MR / 2; ++t) {
+                    const f32x4 lo = acc[2 * t][j], hi = acc[2 * t + 1][j];
+                    u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                    }
+                    const unsigned voff = ok ? (pix * (unsigned)a.Cout + (unsigned)(c0 + cout_lane + 32 * t)) * 2u : kOobOffset;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff, 0, 0);
+                }
+            }
+        }
+    }
+#else
+    (void)a;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Bottleneck tail (layer1): conv3 1x1 (64 -> 256) + bn3 + identity + ReLU, and the NEXT block's
 // conv1 1x1 (256 -> C1) + bn1 + ReLU, in one pass over the pixels.
 // Why: at 56x56 these two layers are HBM-bound (the block output is 2*M*256 bytes, written by conv3 and read

@@ -484,6 +484,39 @@ hipError_t launch_conv3x3_xres(const ConvArgs& a, hipStream_t s) {
     return deep ? launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 4>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3>(a, s);
 }
 
+// conv2 of layer2.0 / layer3.0 (3x3 STRIDE 2 p1, Cin = Cout, 56 -> 28 x 128 and 28 -> 14 x 256): input resident by polyphase planes (kernels.h:
+// conv3x3_s2_kernel); tile id 64+18.  Chosen for these shapes at EVERY batch size: its K order differs from the generic kernel's.
+constexpr int kTileS2 = kWsBit | 18;
+bool is_s2_shape(const ConvArgs& a) {
+    if (!(a.ks == 3 && a.stride == 2 && a.pad == 1 && a.Cin == a.Cout && a.H == a.W && a.res == nullptr && a.x2 == nullptr &&
+          a.x_cstride == a.Cin && a.y_cstride == a.Cout && a.Ktot == 9 * a.Cin && a.et != 2)) return false;
+    return (a.H == 56 && a.Cin == 128) || (a.H == 28 && a.Cin == 256);
+}
+template <int ET, int TR, int OW, int OH>
+hipError_t launch_conv3x3_s2_t(ConvArgs a, hipStream_t s) {
+    constexpr size_t lds = 3 * 32768 + 3 * 128 * 128;
+    auto kern = conv3x3_s2_kernel<ET, 128, TR, OW, OH>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        g_num_cus = cu_budget(prop.multiProcessorCount);
+    }
+    a.n_ctiles = a.Cout / 128;
+    a.n_blocks = a.N * (OH / TR) * a.n_ctiles;
+    const int grid = a.n_blocks < g_num_cus ? a.n_blocks : g_num_cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, s, a);
+    return hipGetLastError();
+}
+template <int ET>
+hipError_t launch_conv3x3_s2(const ConvArgs& a, hipStream_t s) {
+    if (!is_s2_shape(a)) return hipErrorInvalidValue;
+    if (a.H == 56) return launch_conv3x3_s2_t<ET, 7, 28, 28>(a, s);
+    return launch_conv3x3_s2_t<ET, 14, 14, 14>(a, s);
+}
+
 // tiles a launch of tile id `tile` would have (0 if the id does not divide this Cout)
 long long tiles_of(const ConvArgs& a, int tile) {
     int bc = 0, bp = 0;
@@ -505,9 +538,11 @@ long long tiles_of(const ConvArgs& a, int tile) {
 }
 
 int g_use_xres = [] { const char* v = std::getenv("R50_XRES"); return v ? std::atoi(v) : 1; }();      // A/B knob: 0 = generic igemm tiles for the 3x3 s1 shapes
+int g_use_s2 = [] { const char* v = std::getenv("R50_S2"); return v ? std::atoi(v) : 1; }();          // A/B knob: 0 = generic igemm tiles for the 3x3 s2 shapes
 int auto_tile(const ConvArgs& a) {
     if (is_c64_shape(a)) return kTileC64;
     if (g_use_xres && is_xres_shape(a)) return kTileXres;
+    if (g_use_s2 && is_s2_shape(a)) return kTileS2;
     const long long want = 200;           // of 256 CUs: below that a launch leaves too much of the chip idle
     if (a.N >= 48 && a.H == a.W)
         for (const TunedTile& t : kTuned)
@@ -537,10 +572,11 @@ hipError_t launch_igemm_et(const ConvArgs& a, int tile, hipStream_t s, bool spli
         return launch_igemm_t<0, 128, 128, 2, 2, 2, true>(a, false, s);
     }
     if (tile == 0) tile = auto_tile(a);
-    if (a.x2 && (!(tile & kWsBit) || tile == kTileC64 || tile == kTileXres)) return hipErrorInvalidValue;     // two K sources: igemm_ws_kernel only
+    if (a.x2 && (!(tile & kWsBit) || tile == kTileC64 || tile == kTileXres || tile == kTileS2)) return hipErrorInvalidValue;     // two K sources: igemm_ws_kernel only
     const bool pers = (tile & kPersistBit) != 0;
     if (tile == kTileC64) return launch_conv3x3_c64<ET>(a, s);
     if (tile == kTileXres) return launch_conv3x3_xres<ET>(a, s);
+    if (tile == kTileS2) return launch_conv3x3_s2<ET>(a, s);
     if (tile & kWsBit) {
         // <couts, pixels, consumer waves (couts x pixels), loader waves, LDS stages>
         switch (tile & (kPersistBit - 1)) {
@@ -1693,6 +1729,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "fuse_block2") h->fuse_block2 = value ? 1 : 0;
     else if (k == "fuse_block1") { if (value < 0 || value > 2) return fail(h, R50_ERR_INVALID, "fuse_block1 must be 0, 1 or 2"); h->fuse_block1 = (int)value; }
     else if (k == "xres_variant") g_xres_variant = (int)value;        // process-wide A/B knob
+    else if (k == "use_s2") g_use_s2 = (int)value;                     // process-wide A/B knob: 0 = generic tiles for the stride-2 3x3 shapes
     else if (k == "cu_cap") { if (value < 0 || value > 4096) return fail(h, R50_ERR_INVALID, "cu_cap must be in [0,4096]"); g_cu_cap = (int)value; g_num_cus = 0; }
     else return fail(h, R50_ERR_INVALID, "r50_set_option: unknown key " + k);
     return R50_OK;

@@ -30,6 +30,7 @@ TILE_128x256_W16 = 14    # 16 waves, 3 LDS stages, wave tile 32c x 64p
 WS = 64                  # role-specialised kernel (4 loader waves + 4 or 8 consumer waves, one workgroup per CU):
                          # WS|1 = 128x128 (4), WS|3 = 256x128 (8), WS|4 = 128x224 (4), WS|8 = 128x224 (8), WS|9 = 64x224 (4), WS|10 = 128x208 (4)
 TILE_XRES = 81           # 3x3 s1 p1 with Cin = Cout on 28x28 (128), 14x14 (256), 7x7 (512): input resident in LDS, only the weights stream (the automatic choice for these shapes)
+TILE_S2 = 82             # 3x3 STRIDE 2 p1 with Cin = Cout, 56 -> 28 (128) and 28 -> 14 (256): input resident by polyphase planes (the automatic choice for these shapes)
 TILE_C64 = 80            # 3x3 s1 p1 64 -> 64 on 56x56 only (layer1 conv2): filter bank resident in LDS, input staged once per tile
 PERSISTENT = 32          # + PERSISTENT: chip-sized grid, tiles streamed through the LDS ring
 

@@ -59,6 +59,11 @@ CONV_CASES = [
     (5, 7, 7, 512, 512, 3, 1, 1, True, False),
     (3, 28, 28, 128, 128, 3, 1, 1, True, False),
     (3, 14, 14, 256, 256, 3, 1, 1, False, False),
+    # polyphase stride-2 3x3 kernel (TILE_S2: conv2 of layer2.0 / layer3.0): four row bands per image at 56 -> 28 (top / bottom borders in
+    # different bands), one image per tile at 28 -> 14, two cout tiles; every generic tile runs the same case beside it
+    (3, 56, 56, 128, 128, 3, 2, 1, True, False),
+    (2, 28, 28, 256, 256, 3, 2, 1, True, False),
+    (1, 28, 28, 256, 256, 3, 2, 1, False, False),
 ]
 
 
@@ -101,6 +106,8 @@ def test_conv2d_matches_oracle(lib_built, case):
         tiles = tiles + [ops.TILE_C64]
     if (k, stride, pad, has_res) == (3, 1, 1, False) and (h, w, cin, cout) in ((28, 28, 128, 128), (14, 14, 256, 256), (7, 7, 512, 512)):
         tiles = tiles + [ops.TILE_XRES]
+    if (k, stride, pad, has_res) == (3, 2, 1, False) and (h, w, cin, cout) in ((56, 56, 128, 128), (28, 28, 256, 256)):
+        tiles = tiles + [ops.TILE_S2]
     for tile in tiles:
         # guard band behind the result: the tile rows past M (ragged last tile) must not be stored anywhere
         numel = n * ho * wo * cout
@@ -144,6 +151,30 @@ def test_xres_schedule_variants_bit_identical(lib_built, shape):
     finally:
         bb.set_option("xres_variant", 0)
         bb.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 56, 128), (70, 56, 128), (300, 56, 128), (5, 28, 256), (300, 28, 256)],
+                         ids=lambda v: "n%d_%dx%d_c%d" % (v[0], v[1], v[1], v[2]))
+def test_s2_kernel_is_batch_invariant_and_stays_inside_its_output(lib_built, shape):
+    """conv3x3_s2_kernel with several tiles per workgroup (n = 300: 1,200 / 600 tiles on 256 CUs: the plane stream crosses tile borders,
+    the loader re-decodes its offsets in mid-stream): every image's result is the same bits as when the image is run alone, and nothing
+    is stored past the output (poisoned guard band)."""
+    from implementation_phd_lab_vision_amd import ops
+    n, hw, c = shape
+    g = torch.Generator().manual_seed(n * 100 + hw)
+    d = _dev()
+    x = _rand_bf16((n, hw, hw, c), g).to(d)
+    wt = _rand_bf16((c, 3, 3, c), g, scale=(2.0 / (9 * c)) ** 0.5).to(d)
+    bias = (torch.randn(c, generator=g) * 0.1).to(d)
+    ho = hw // 2
+    numel = n * ho * ho * c
+    buf = torch.full((numel + 512 * c,), -7.0, dtype=torch.bfloat16, device=d)
+    y = ops.conv2d_bf16(x, wt, bias, stride=2, pad=1, relu=True, tile=ops.TILE_S2, out=buf)
+    torch.cuda.synchronize()
+    assert bool((buf[numel:] == -7.0).all()), "wrote past the end of the output"
+    for i in sorted({0, n // 2, n - 1}):
+        alone = ops.conv2d_bf16(x[i:i + 1].contiguous(), wt, bias, stride=2, pad=1, relu=True, tile=ops.TILE_S2)
+        assert torch.equal(alone[0], y[i]), f"image {i} of {n} differs from the same image run alone"
 
 
 @pytest.mark.parametrize("chain", [False, True], ids=["last_block", "chained_conv1"])
