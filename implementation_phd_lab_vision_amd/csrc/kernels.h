@@ -1050,10 +1050,17 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
 template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST, int SCHED = 0, int RB = 0>
 __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(RB == 0 || (NI == 1 && (IW == 14 || IW == 28) && TR * (IW == 14 ? 16 : 32) == 224 && TPS == 1 && NST == 3 && SCHED == 0), "row blocks: 14 blocks of 16 positions");
+    // RB 1 at 7x7 (NI = 4): a row of 16 positions holds the same image row of TWO images with shared zero columns, [0 | A0..A6 | 0 | B0..B6] (B's right
+    // border is the next row's first position), and the two image pairs sit on top of each other with a shared zero row: 17 rows.  An output row
+    // (16 slots, 14 of them pixels: the 12.5 % of the 14x14 form) is one block; blocks 0..6 = pair 0, 8..14 = pair 1 (block 7 is the shared
+    // zero row and is never computed): wave half p takes blocks 8 p + 0..6.
+    constexpr bool RB7 = RB && IW == 7;
+    static_assert(RB == 0 || (TPS == 1 && NST == 3 && SCHED == 0 && ((NI == 1 && (IW == 14 || IW == 28) && TR * (IW == 14 ? 16 : 32) == 224) || (NI == 4 && IW == 7 && TR == 7 && RB == 1))),
+                  "row blocks: 14 blocks of 16 positions");
     static_assert(RB != 3 || BC == 128, "32-wide blocks: four consumer waves of 32 couts");
     constexpr int NCW = RB == 3 ? 4 : 8;                              // consumer waves
-    constexpr int PW = RB ? (IW == 14 ? 16 : 32) : IW + 2, PP = (TR + 2) * PW, PPT = NI * PP;     // padded positions per panel / per tile
+    constexpr int PW = RB ? (IW == 28 ? 32 : 16) : IW + 2, PP = (TR + 2) * PW, PPT = RB7 ? 17 * 16 : NI * PP;     // padded positions per panel / per tile
+    constexpr int BSTEP = RB7 ? 8 : 7;                                // first block of the second slot half
     constexpr int XPASS = (PPT + 31) / 32, XBUF = XPASS * 32 * 128;
     constexpr int NPX = NI * TR * IW, NBLK = RB ? 14 : (NPX + 15) / 16;         // 196 pixels, 13 blocks (row blocks: 14)
     static_assert(RB || NBLK == 13, "tiles are 196 pixels");
@@ -1110,9 +1117,14 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
 #pragma unroll
             for (int i = 0; i < XPASS; ++i) {
                 const int q = i * 32 + srow;
-                const int panel = q / PP, rem = q - panel * PP;
-                const int rr = rem / PW, cc = rem - rr * PW;
-                const int n = n0 + panel, y = band * TR + rr - 1, x = cc - 1;
+                int panel = q / PP, rem = q - panel * PP;
+                int rr = rem / PW, cc = rem - rr * PW;
+                int n = n0 + panel, y = band * TR + rr - 1, x = cc - 1;
+                if constexpr (RB7) {              // row rho = q / 16 of 17, column kappa = q % 16: pair rho >= 9, image of the pair kappa >= 8
+                    rr = q >> 4; cc = q & 15; panel = 0;
+                    const int pr = rr >= 9 ? 1 : 0;
+                    n = n0 + 2 * pr + (cc >> 3); y = rr - 1 - 8 * pr; x = (cc & 7) - 1;
+                }
                 const bool ok = q < PPT && tile < n_tiles && n < a.N && (unsigned)y < (unsigned)IH && (unsigned)x < (unsigned)IW;
                 // 16-B chunk c of a position is stored at c ^ key, key = (panel * TR * IW + rr * IW + cc) & 7: for the 16 consecutive output pixels
                 // of an MFMA column block the positions a tap reads then have CONSECUTIVE keys also across row and image wraps (keyed on the
@@ -1561,7 +1573,7 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
         auto run_steps_rb = [&]() {
             constexpr int NRW = 7, PD = XRES_PD;
             constexpr bool W2 = (MR <= 2);
-            const char* const xl = smem + 7 * 2048 * wave_p;           // this pixel half's first block
+            const char* const xl = smem + BSTEP * 2048 * wave_p;       // this pixel half's first block
             int vb[3][2];                                               // [tap column][K half]: position fr + kw, chunk (fq + 4 kk) ^ key
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw)
@@ -1624,11 +1636,13 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
                 }
                 // ---- epilogue: ReLU, 16-bit, one 16-B store per valid slot and block pair (slot = 16 b + fr = padded row * PW + column)
                 const int pt = tile / nct;
-                const int band = pt % NB, n = pt / NB;
+                const int band = pt % NB;
+                int n = pt / NB;
 #pragma unroll
                 for (int j = 0; j < NRW; ++j) {
-                    const int sl = 16 * (7 * wave_p + j) + fr;
-                    const int r = sl / PW, cx = sl - r * PW;
+                    const int sl = 16 * (BSTEP * wave_p + j) + fr;
+                    int r = sl / PW, cx = sl - r * PW;
+                    if constexpr (RB7) { n = (pt / NB) * NI + 2 * wave_p + (fr >> 3); r = j; cx = fr & 7; }     // block 8 p + j = row j of image pair p
                     const bool ok = cx < IW && n < a.N;
                     const unsigned pix = (unsigned)((n * IH + band * TR + r) * IW + cx);
 #pragma unroll

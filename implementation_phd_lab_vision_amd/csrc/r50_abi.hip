@@ -413,8 +413,8 @@ bool is_xres_shape(const ConvArgs& a) {
 }
 template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST, int SCHED = 0, int RB = 0>
 hipError_t launch_conv3x3_xres_t(ConvArgs a, hipStream_t s) {
-    constexpr int PW = RB ? (IW == 14 ? 16 : 32) : IW + 2;
-    constexpr int PPT = NI * (TR + 2) * PW, XBUF = (PPT + 31) / 32 * 32 * 128;
+    constexpr int PW = RB ? (IW == 28 ? 32 : 16) : IW + 2;
+    constexpr int PPT = (RB && IW == 7) ? 17 * 16 : NI * (TR + 2) * PW, XBUF = (PPT + 31) / 32 * 32 * 128;
     constexpr size_t lds = 2 * (size_t)XBUF + NST * (size_t)TPS * BC * 128;
     static_assert(lds <= 163840, "LDS budget");
     auto kern = conv3x3_xres_kernel<ET, BC, NI, TR, IW, IH, TPS, NST, SCHED, RB>;
@@ -442,7 +442,7 @@ hipError_t launch_conv3x3_xres(const ConvArgs& a, hipStream_t s) {
     // Round 3: the DEFAULT at 14x14 and 28x28 is the row-block form (variant 10: no address arithmetic in the K loop; bit-identical to the
     // 13-block form, 55.0 -> 51.2 us and 60.6 -> 57.2 us at batch 256, profiles/r03_xres_variants.txt).  Variant 20 = the round-2 default.
     int var = g_xres_variant;                     // A/B knob (R50_XRES_VARIANT / option "xres_variant")
-    if (var == 0 && (a.H == 14 || a.H == 28)) var = 10;
+    if (var == 0) var = 10;
     if (var == 20) var = 0;
     const bool deep = (var == 4);                  // ring of 4 weight stages (3 in flight) instead of 3
     if (var == 6) {                                // mid-step barrier schedule + deeper weight ring (5 / 4 / 5 stages: 4 / 3 / 4 in flight)
@@ -458,6 +458,7 @@ hipError_t launch_conv3x3_xres(const ConvArgs& a, hipStream_t s) {
     if (var == 10 || var == 11) {                  // row blocks (kernels.h, RB 1): no address arithmetic in the K loop; 11 = 256 couts per tile at 14x14
         if (a.H == 14) return var == 11 ? launch_conv3x3_xres_t<ET, 256, 1, 14, 14, 14, 1, 3, 0, 1>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 0, 1>(a, s);
         if (a.H == 28) return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3, 0, 1>(a, s);
+        if (a.H == 7 && var == 10) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 3, 0, 1>(a, s);      // image pairs per row (kernels.h, RB7)
     }
     if (var == 13) {                               // row blocks on the 32x32x16 MFMA, four consumer waves (kernels.h, RB 3)
         if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 0, 3>(a, s);
