@@ -1024,9 +1024,10 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
 // batch size (a frame's features must not depend on the batch it travels in).
 // 8 consumer waves (cout group w & 3, pixel half w >> 2: blocks 0..6 / 7..12; waves w and w + 4 share a SIMD) + 4 loader waves.
 // ------------------------------------------------------------------------------------------------
-// Diagnostic ablations (scripts/build_variant.sh -DXRES_ABL=mask; timing only, results are wrong; consumer bits act on SCHED 1 only):
+// Diagnostic ablations (scripts/build_variant.sh -DXRES_ABL=mask; timing only, results are wrong; consumer bits act on SCHED 1 and on RB 1):
 // 1 = pixel-fragment addresses without the per-tap arithmetic, 4 = no stores, 8 = no MFMAs (reads stay live), 16 = no pixel-fragment
-// reads, 32 = every LDS-DMA zero-fills (issued, no L2 traffic), 64 = the loaders issue no DMA at all (barriers only), 128 = no per-step barrier
+// reads, 32 = every LDS-DMA zero-fills (issued, no L2 traffic), 64 = the loaders issue no DMA at all (barriers only), 128 = no per-step barrier,
+// 256 = no weight DMAs (input DMAs stay), 512 = no input DMAs (weight DMAs stay)
 #ifndef XRES_ABL
 #define XRES_ABL 0
 #endif
@@ -1144,7 +1145,7 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
 #pragma unroll
             for (int i = 0; i < XPASS; ++i)
                 if (i >= p0 && i < p1)
-                    if (!(XRES_ABL & 64)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + x_par * XBUF + i * 4096 + lw * 1024), 16, x_voff[i], xofs, 0, 0);
+                    if (!(XRES_ABL & (64 | 512))) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + x_par * XBUF + i * 4096 + lw * 1024), 16, x_voff[i], xofs, 0, 0);
         };
         // X passes issued beside tap s of a chunk: taps 2..8 carry two passes each (the buffer being refilled was read until tap 8 of the
         // PREVIOUS chunk, and this loader runs at most D = 2 steps ahead of the consumers)
@@ -1176,7 +1177,7 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
             char* sbase = smem + WRING + i_buf * WSTAGE + lw * 1024;
 #pragma unroll
             for (int i = 0; i < WPASS; ++i)
-                if (!(XRES_ABL & 64)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LDS_AS void*)(sbase + i * 4096), 16, w_voff[i], wofs, 0, 0);
+                if (!(XRES_ABL & (64 | 256))) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LDS_AS void*)(sbase + i * 4096), 16, w_voff[i], wofs, 0, 0);
             const bool has_next_chunk = (g / SPC) + 1 < my_tiles * cch;
             if (has_next_chunk && i_s >= XS0) x_issue(xp_lo(i_s), xp_hi(i_s));
             i_buf = (i_buf == NSTAGE - 1) ? 0 : i_buf + 1;
@@ -1600,7 +1601,10 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
                         const char* const x1 = xc + vb[kw][1] + kh * 2048 * (PW / 16);
                         const char* const w0 = wl0 + (tap % 3) * WSTAGE;
                         const char* const w1 = wl1 + (tap % 3) * WSTAGE;
-                        auto xread = [&](int t) { return *reinterpret_cast<const bf16x8*>((t >= NRW ? x1 : x0) + (t % NRW) * 2048); };
+                        auto xread = [&](int t) {
+                            if constexpr (XRES_ABL & 16) return __builtin_bit_cast(bf16x8, (u32x4){(unsigned)(size_t)x0, 1u, 2u, (unsigned)t});
+                            else return *reinterpret_cast<const bf16x8*>((t >= NRW ? x1 : x0) + (t % NRW) * 2048);
+                        };
                         bf16x8 x[2 * NRW], wf[MR], wg[W2 ? MR : 1];
 #pragma unroll
                         for (int m = 0; m < MR; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(w0 + m * 2048);
@@ -1619,7 +1623,10 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
                                 }
                             }
 #pragma unroll
-                            for (int m = 0; m < MR; ++m) acc[m][t % NRW] = mfma_e<ET>((W2 && t >= NRW) ? wg[m] : wf[m], x[t], acc[m][t % NRW]);
+                            for (int m = 0; m < MR; ++m) {
+                                if constexpr (XRES_ABL & 8) { asm volatile("" ::"v"((W2 && t >= NRW) ? wg[m] : wf[m]), "v"(x[t])); }
+                                else acc[m][t % NRW] = mfma_e<ET>((W2 && t >= NRW) ? wg[m] : wf[m], x[t], acc[m][t % NRW]);
+                            }
                             if (t + PD < 2 * NRW) x[t + PD] = xread(t + PD);
                         }
                         __builtin_amdgcn_sched_group_barrier(0x100, (W2 ? 2 * MR : MR) + PD, 0);
@@ -1630,7 +1637,7 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
                             if (t + PD < 2 * NRW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);              // the barrier stays behind the step's last fragment read
-                        __builtin_amdgcn_s_barrier();
+                        if (!(XRES_ABL & 128)) __builtin_amdgcn_s_barrier();
                     }
                     x_par ^= 1;
                 }
@@ -1654,7 +1661,7 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
                             for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
                         }
                         const unsigned voff = ok ? (pix * (unsigned)a.Cout + (unsigned)(c0 + cout_lane + 32 * t)) * 2u : kOobOffset;
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff, 0, 0);
+                        if (!(XRES_ABL & 4) || o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff, 0, 0);
                     }
                 }
             }
@@ -1823,14 +1830,20 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
 //     OO of c + 1    0..3      6 (4), 7 (4)                 window [6, 7]
 // 8 consumer waves (cout group w & 3, slot half w >> 2: 7 + 7 blocks) + 4 loader waves, as the stride-1 kernel.
 // ------------------------------------------------------------------------------------------------
+// 14 -> 7 (layer4.0, OW = 7): FOUR images per tile as two pairs; a plane row of 16 positions holds plane row R of both images of a pair
+// ([A i = 0..7 | B i = 0..7], i = 0 being x = -1 on the odd-column planes), the pairs' 8 plane rows sit on top of each other (16 rows = 256
+// positions); an output row of a pair (16 slots, 14 of them pixels) is one block, blocks 8 p + 0..6 = pair p (as the 7x7 row-block form of
+// conv3x3_xres_kernel).
 template <int ET, int BC, int TR, int OW, int OH>
 __global__ __launch_bounds__(768) void conv3x3_s2_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int PW = OW == 14 ? 16 : 32;
-    static_assert((OW == 14 || OW == 28) && TR * PW == 224 && OH % TR == 0 && BC == 128, "14 blocks of 16 slots, 128 couts");
+    constexpr bool PAIR = OW == 7;
+    constexpr int PW = OW == 28 ? 32 : 16;
+    static_assert(BC == 128 && (PAIR ? (TR == 7 && OH == 7) : ((OW == 14 || OW == 28) && TR * PW == 224 && OH % TR == 0)), "14 blocks of 16 slots, 128 couts");
     constexpr int IH = 2 * OH, IW = 2 * OW, NB = OH / TR;
+    constexpr int NIMG = PAIR ? 4 : 1, BSTEP = PAIR ? 8 : 7;          // images per tile; first block of the second slot half
     constexpr int XPASS = 8, XBUF = XPASS * 32 * 128;                  // (TR + 1) * PW <= 256 positions
-    static_assert((TR + 1) * PW <= 256, "plane buffer");
+    static_assert(PAIR || (TR + 1) * PW <= 256, "plane buffer");
     constexpr int MR = BC / 64, WPASS = BC / 32, WSTAGE = BC * 128, NST = 3, D = 2;
     constexpr int WRING = 3 * XBUF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1861,14 +1874,15 @@ __global__ __launch_bounds__(768) void conv3x3_s2_kernel(const ConvArgs a) {
         };
         auto decode_x = [&](int tile) {           // per plane (py, px): source offset of plane position (R, i) or out of range (zero border)
             const int pt = tile / nct;
-            const int band = pt % NB, n = pt / NB;
+            const int band = pt % NB;
 #pragma unroll
             for (int ph = 0; ph < 4; ++ph) {
                 const int py = ph >> 1, px = ph & 1;
 #pragma unroll
                 for (int i = 0; i < XPASS; ++i) {
                     const int q = i * 32 + srow;
-                    const int R = q / PW, ii = q - R * PW;
+                    int R = q / PW, ii = q - R * PW, n = (pt / NB) * NIMG;
+                    if constexpr (PAIR) { n += 2 * (R >> 3) + (ii >> 3); R &= 7; ii &= 7; }       // row 8 p + R of pair p, column 8 (image of the pair) + i
                     const int y = 2 * (band * TR + R) - 1 + py, x = 2 * ii - 1 + px;
                     const bool ok = tile < n_tiles && n < a.N && R <= TR && (unsigned)y < (unsigned)IH && (unsigned)x < (unsigned)IW;
                     x_voff[ph][i] = ok ? (unsigned)(((n * IH + y) * IW + x) * a.Cin + (slot ^ (ii & 7)) * 8) * 2u : kOobOffset;
@@ -1974,7 +1988,7 @@ __global__ __launch_bounds__(768) void conv3x3_s2_kernel(const ConvArgs a) {
                     // step s of the chunk: plane, offset (dr, dc) on the plane (the loader's tap order)
                     const int dr = (s < 4) ? (s >> 1) : (s < 6) ? (s - 4) : 0;
                     const int dc = (s < 4) ? (s & 1) : (s >= 6 && s < 8) ? (s - 6) : 0;
-                    const char* const xc = smem + x_buf * XBUF + 7 * 2048 * wave_p + dr * (PW * 128);
+                    const char* const xc = smem + x_buf * XBUF + BSTEP * 2048 * wave_p + dr * (PW * 128);
                     const char* const x0 = xc + vb[dc][0];
                     const char* const x1 = xc + vb[dc][1];
                     const char* const w0 = wl0 + (s % 3) * WSTAGE;
@@ -2006,11 +2020,14 @@ __global__ __launch_bounds__(768) void conv3x3_s2_kernel(const ConvArgs a) {
             }
             // ---- epilogue: ReLU, 16-bit, one 16-B store per valid slot and block pair (slot = 16 b + fr = output row * PW + column)
             const int pt = tile / nct;
-            const int band = pt % NB, n = pt / NB;
+            const int band = pt % NB;
+            int n = (pt / NB) * NIMG;
+            if constexpr (PAIR) n += 2 * wave_p + (fr >> 3);
 #pragma unroll
             for (int j = 0; j < NRW; ++j) {
-                const int sl = 16 * (7 * wave_p + j) + fr;
-                const int r = sl / PW, cx = sl - r * PW;
+                const int sl = 16 * (BSTEP * wave_p + j) + fr;
+                int r = sl / PW, cx = sl - r * PW;
+                if constexpr (PAIR) { r = j; cx = fr & 7; }
                 const bool ok = cx < OW && n < a.N;
                 const unsigned pix = (unsigned)((n * OH + band * TR + r) * OW + cx);
 #pragma unroll

@@ -485,13 +485,13 @@ hipError_t launch_conv3x3_xres(const ConvArgs& a, hipStream_t s) {
     return deep ? launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 4>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3>(a, s);
 }
 
-// conv2 of layer2.0 / layer3.0 (3x3 STRIDE 2 p1, Cin = Cout, 56 -> 28 x 128 and 28 -> 14 x 256): input resident by polyphase planes (kernels.h:
+// conv2 of layer2.0 / layer3.0 / layer4.0 (3x3 STRIDE 2 p1, Cin = Cout, 56 -> 28 x 128, 28 -> 14 x 256, 14 -> 7 x 512): input resident by polyphase planes (kernels.h:
 // conv3x3_s2_kernel); tile id 64+18.  Chosen for these shapes at EVERY batch size: its K order differs from the generic kernel's.
 constexpr int kTileS2 = kWsBit | 18;
 bool is_s2_shape(const ConvArgs& a) {
     if (!(a.ks == 3 && a.stride == 2 && a.pad == 1 && a.Cin == a.Cout && a.H == a.W && a.res == nullptr && a.x2 == nullptr &&
           a.x_cstride == a.Cin && a.y_cstride == a.Cout && a.Ktot == 9 * a.Cin && a.et != 2)) return false;
-    return (a.H == 56 && a.Cin == 128) || (a.H == 28 && a.Cin == 256);
+    return (a.H == 56 && a.Cin == 128) || (a.H == 28 && a.Cin == 256) || (a.H == 14 && a.Cin == 512);
 }
 template <int ET, int TR, int OW, int OH>
 hipError_t launch_conv3x3_s2_t(ConvArgs a, hipStream_t s) {
@@ -506,7 +506,7 @@ hipError_t launch_conv3x3_s2_t(ConvArgs a, hipStream_t s) {
         g_num_cus = cu_budget(prop.multiProcessorCount);
     }
     a.n_ctiles = a.Cout / 128;
-    a.n_blocks = a.N * (OH / TR) * a.n_ctiles;
+    a.n_blocks = (OW == 7 ? (a.N + 3) / 4 : a.N * (OH / TR)) * a.n_ctiles;
     const int grid = a.n_blocks < g_num_cus ? a.n_blocks : g_num_cus;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, s, a);
     return hipGetLastError();
@@ -515,6 +515,7 @@ template <int ET>
 hipError_t launch_conv3x3_s2(const ConvArgs& a, hipStream_t s) {
     if (!is_s2_shape(a)) return hipErrorInvalidValue;
     if (a.H == 56) return launch_conv3x3_s2_t<ET, 7, 28, 28>(a, s);
+    if (a.H == 14) return launch_conv3x3_s2_t<ET, 7, 7, 7>(a, s);          // four images per tile (two pairs)
     return launch_conv3x3_s2_t<ET, 14, 14, 14>(a, s);
 }
 

@@ -7,7 +7,7 @@ _lib.load_library()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 d = torch.device('cuda:0'); g = torch.Generator().manual_seed(0)
-for hw, c, tuned in ((56, 128, 65), (28, 256, 44)):
+for hw, c, tuned in ((56, 128, 65), (28, 256, 44), (14, 512, 68)):
     x = torch.randn((B, hw, hw, c), generator=g).to(torch.bfloat16).to(d)
     w = (torch.randn((c, 3, 3, c), generator=g) * (2.0 / (9 * c)) ** 0.5).to(torch.bfloat16).to(d)
     b = torch.randn(c, generator=g).to(d)

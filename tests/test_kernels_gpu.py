@@ -64,6 +64,7 @@ CONV_CASES = [
     (3, 56, 56, 128, 128, 3, 2, 1, True, False),
     (2, 28, 28, 256, 256, 3, 2, 1, True, False),
     (1, 28, 28, 256, 256, 3, 2, 1, False, False),
+    (5, 14, 14, 512, 512, 3, 2, 1, True, False),   # 14 -> 7: four images per tile (two pairs), the second tile holds one image
 ]
 
 
@@ -106,7 +107,7 @@ def test_conv2d_matches_oracle(lib_built, case):
         tiles = tiles + [ops.TILE_C64]
     if (k, stride, pad, has_res) == (3, 1, 1, False) and (h, w, cin, cout) in ((28, 28, 128, 128), (14, 14, 256, 256), (7, 7, 512, 512)):
         tiles = tiles + [ops.TILE_XRES]
-    if (k, stride, pad, has_res) == (3, 2, 1, False) and (h, w, cin, cout) in ((56, 56, 128, 128), (28, 28, 256, 256)):
+    if (k, stride, pad, has_res) == (3, 2, 1, False) and (h, w, cin, cout) in ((56, 56, 128, 128), (28, 28, 256, 256), (14, 14, 512, 512)):
         tiles = tiles + [ops.TILE_S2]
     for tile in tiles:
         # guard band behind the result: the tile rows past M (ragged last tile) must not be stored anywhere
@@ -153,7 +154,7 @@ def test_xres_schedule_variants_bit_identical(lib_built, shape):
         bb.close()
 
 
-@pytest.mark.parametrize("shape", [(1, 56, 128), (70, 56, 128), (300, 56, 128), (5, 28, 256), (300, 28, 256)],
+@pytest.mark.parametrize("shape", [(1, 56, 128), (70, 56, 128), (300, 56, 128), (5, 28, 256), (300, 28, 256), (3, 14, 512), (300, 14, 512)],
                          ids=lambda v: "n%d_%dx%d_c%d" % (v[0], v[1], v[1], v[2]))
 def test_s2_kernel_is_batch_invariant_and_stays_inside_its_output(lib_built, shape):
     """conv3x3_s2_kernel with several tiles per workgroup (n = 300: 1,200 / 600 tiles on 256 CUs: the plane stream crosses tile borders,
