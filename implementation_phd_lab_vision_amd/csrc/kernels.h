@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
     // (16 slots, 14 of them pixels: the 12.5 % of the 14x14 form) is one block; blocks 0..6 = pair 0, 8..14 = pair 1 (block 7 is the shared
     // zero row and is never computed): wave half p takes blocks 8 p + 0..6.
     constexpr bool RB7 = RB && IW == 7;
-    static_assert(RB == 0 || (TPS == 1 && NST == 3 && SCHED == 0 && ((NI == 1 && (IW == 14 || IW == 28) && TR * (IW == 14 ? 16 : 32) == 224) || (NI == 4 && IW == 7 && TR == 7 && RB == 1))),
+    static_assert(RB == 0 || (TPS == 1 && (NST == 3 || RB == 1) && SCHED == 0 && ((NI == 1 && (IW == 14 || IW == 28) && TR * (IW == 14 ? 16 : 32) == 224) || (NI == 4 && IW == 7 && TR == 7 && RB == 1))),
                   "row blocks: 14 blocks of 16 positions");
     static_assert(RB != 3 || BC == 128, "32-wide blocks: four consumer waves of 32 couts");
     constexpr int NCW = RB == 3 ? 4 : 8;                              // consumer waves
@@ -1599,8 +1599,10 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
                         const int kh = tap / 3, kw = tap - 3 * kh;
                         const char* const x0 = xc + vb[kw][0] + kh * 2048 * (PW / 16);
                         const char* const x1 = xc + vb[kw][1] + kh * 2048 * (PW / 16);
-                        const char* const w0 = wl0 + (tap % 3) * WSTAGE;
-                        const char* const w1 = wl1 + (tap % 3) * WSTAGE;
+                        // ring slot: static with three stages (9 taps per chunk); a deeper ring (A/B knob) carries a running slot index
+                        const char* const w0 = wl0 + (NSTAGE == 3 ? tap % 3 : c_buf) * WSTAGE;
+                        const char* const w1 = wl1 + (NSTAGE == 3 ? tap % 3 : c_buf) * WSTAGE;
+                        if constexpr (NSTAGE != 3) c_buf = (c_buf == NSTAGE - 1) ? 0 : c_buf + 1;
                         auto xread = [&](int t) {
                             if constexpr (XRES_ABL & 16) return __builtin_bit_cast(bf16x8, (u32x4){(unsigned)(size_t)x0, 1u, 2u, (unsigned)t});
                             else return *reinterpret_cast<const bf16x8*>((t >= NRW ? x1 : x0) + (t % NRW) * 2048);

@@ -460,6 +460,11 @@ hipError_t launch_conv3x3_xres(const ConvArgs& a, hipStream_t s) {
         if (a.H == 28) return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3, 0, 1>(a, s);
         if (a.H == 7 && var == 10) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 3, 0, 1>(a, s);      // image pairs per row (kernels.h, RB7)
     }
+    if (var == 14) {                               // row blocks with a deeper weight ring (5 stages, 4 in flight)
+        if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 5, 0, 1>(a, s);
+        if (a.H == 28) return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 5, 0, 1>(a, s);
+        if (a.H == 7) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 5, 0, 1>(a, s);
+    }
     if (var == 13) {                               // row blocks on the 32x32x16 MFMA, four consumer waves (kernels.h, RB 3)
         if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 0, 3>(a, s);
         if (a.H == 28) return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3, 0, 3>(a, s);

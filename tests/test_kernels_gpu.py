@@ -137,8 +137,8 @@ def test_xres_schedule_variants_bit_identical(lib_built, shape):
     try:
         ref = None
         # 0 = default (row blocks at 14x14 / 28x28), 20 = the 13-block form, 5-7 mid-step barrier / deeper rings, 8 staggered SIMD partners,
-        # 12 row blocks + mid-step barrier, 13 row blocks on the 32x32x16 MFMA with four consumer waves
-        for var in (20, 0, 5, 6, 7, 8, 10, 12, 13, 0):
+        # 12 row blocks + mid-step barrier, 13 row blocks on the 32x32x16 MFMA with four consumer waves, 14 row blocks with a ring of 5 weight stages
+        for var in (20, 0, 5, 6, 7, 8, 10, 12, 13, 14, 0):
             bb.set_option("xres_variant", var)
             numel = n * hw * hw * c
             buf = torch.full((numel + 512 * c,), -7.0, dtype=torch.bfloat16, device=d)
