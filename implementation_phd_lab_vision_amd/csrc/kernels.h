@@ -2083,6 +2083,19 @@ struct TailArgs {
 #ifndef TAIL_AUX
 #define TAIL_AUX 0
 #endif
+// finer A/B knobs of the layer1 tail's streams (aux bits: 2 = nt): identity loads, block-output stores, conv2-output loads, next-t1 stores
+#ifndef TAIL_LD_AUX
+#define TAIL_LD_AUX TAIL_AUX
+#endif
+#ifndef TAIL_ST_AUX
+#define TAIL_ST_AUX TAIL_AUX
+#endif
+#ifndef TAIL_X_AUX
+#define TAIL_X_AUX 0
+#endif
+#ifndef TAIL_Y1_AUX
+#define TAIL_Y1_AUX 0
+#endif
 
 template <int ET, int C1, bool DS, int NT>
 __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
@@ -2147,13 +2160,13 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
     auto first_loads = [&](int tile, u32x4 (&xf)[2], u32x4 (&rs)[NRS]) {
         const unsigned pix = (unsigned)(tile * 16 + fr);           // past M: the descriptor returns zeros
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) xf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_y2, pix * 128u + kk * 64 + fq * 16, 0, 0);
+        for (int kk = 0; kk < 2; ++kk) xf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_y2, pix * 128u + kk * 64 + fq * 16, 0, TAIL_X_AUX);
         if constexpr (DS) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) rs[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix * 128u + kk * 64 + fq * 16, 0, 0);
         } else {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix * 512u + t * 64 + fq * 16, 0, TAIL_AUX);
+            for (int t = 0; t < 8; ++t) rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix * 512u + t * 64 + fq * 16, 0, TAIL_LD_AUX);
         }
     };
     // TAIL_PF register sets, used round robin (loop unrolled by TAIL_PF so they are indexed statically): a set's loads for
@@ -2204,15 +2217,15 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
             outp[t] = o;
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, pix * 512u + t * 64 + fq * 16, 0, TAIL_AUX);
-            if constexpr (!DS) rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix_n * 512u + t * 64 + fq * 16, 0, TAIL_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, pix * 512u + t * 64 + fq * 16, 0, TAIL_ST_AUX);
+            if constexpr (!DS) rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix_n * 512u + t * 64 + fq * 16, 0, TAIL_LD_AUX);
         }
         if constexpr (DS) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) rs[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix_n * 128u + kk * 64 + fq * 16, 0, 0);
         }
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) xf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_y2, pix_n * 128u + kk * 64 + fq * 16, 0, 0);
+        for (int kk = 0; kk < 2; ++kk) xf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_y2, pix_n * 128u + kk * 64 + fq * 16, 0, TAIL_X_AUX);
         // ---- next conv1: (C1 x 256) x (256 x 16 pixels), K blocks straight from outp
         f32x4 acc2[M2];
 #pragma unroll
@@ -2236,7 +2249,7 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
                               pack2_e<ET>(hi[2], hi[3])};
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, pix * (C1 * 2u) + t2 * 64 + fq * 16, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, pix * (C1 * 2u) + t2 * 64 + fq * 16, 0, TAIL_Y1_AUX);
         }
         };
     u32x4 xfA[2], rsA[NRS], xfB[2], rsB[NRS];
