@@ -2822,7 +2822,7 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
 //         consumers add the identity and store the block output themselves (fragment-shaped accesses)
 // Summation orders are those of the launches this replaces (bias first, K ascending, identity last with the same fp32 additions):
 // block output and next t1 are bit-identical to conv3x3_xres + igemm launches.
-// LDS, C1N = 128: XB0 | XB1 2 x 36,864 (270 padded positions x 128 B, chunk c of position q at c ^ (q & 7)); T2 2 x 26,624 at 0 and OUTC
+// LDS, C1N = 128: XB0 | XB1 2 x 36,864 (288 padded positions x 128 B -- 9 rows of 32, round 3 -- chunk c of a position at c ^ (column & 7)); T2 2 x 26,624 at 0 and OUTC
 // 26,624 at 53,248 overlay them once conv2 is done; RESB 28,672 (224 rows: 7 DMA passes); ring 3 x 16,384; biases 3,072 = 160,768 B.  The
 // next tile's XB0 can only be fetched once T2 is dead (last position), XB1 at the next tile's first position (needed nine stages later).
 // C1N = 0: no OUTC / RESB, T2 at 53,248 (behind XB0, so the next tile's first chunk is fetched two positions early) = 158,720 B.
@@ -2852,7 +2852,9 @@ template <int ET, int C1N>
 __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(C1N == 0 || C1N == 128, "next conv1: none or 512 -> 128");
-    constexpr int IW = 28, TR = 7, PW = IW + 2, PP = (TR + 2) * PW;       // 270 padded positions
+    // (round 3) the band is held in the ROW-BLOCK form of conv3x3_xres_kernel: padded row = 32 positions, an MFMA column block of conv2 = 16
+    // consecutive positions (half an image row: 14 blocks, 7 per slot half), fragment address = lane constant + immediate, taps unrolled
+    constexpr int IW = 28, TR = 7, PW = 32, PP = (TR + 2) * PW;           // 288 padded positions
     constexpr int XPASS = (PP + 31) / 32, XBUF = XPASS * 32 * 128;        // 9 passes, 36,864 B per 64-channel chunk
     constexpr int NPX = TR * IW;                                          // 196
     constexpr int SLOT = 208 * 128;                                       // one 64-channel K-slot of 208 pixel rows
@@ -2915,9 +2917,8 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
                 const int rr = q / PW, cc = q - rr * PW;
                 const int y = band * TR + rr - 1, x = cc - 1;
                 const bool ok = q < PP && tile < a.n_tiles && (unsigned)y < 28u && (unsigned)x < 28u;
-                // chunk key of a position = (rr * IW + cc) & 7, so that a tap's reads of 16 consecutive pixels have consecutive keys across row wraps
-                // (conv3x3_xres_kernel: keyed on q, 23-41 % of the LDS cycles were bank conflicts)
-                x_voff[i] = (ok && !(B2_ABL & 4)) ? (unsigned)(((n * 28 + y) * 28 + x) * 128 + (slot ^ ((rr * IW + cc) & 7)) * 8) * 2u : kOobOffset;
+                // chunk key of a position = its column's, cc & 7 (PW = 0 mod 8): the same for every block and kernel row a lane reads it for
+                x_voff[i] = (ok && !(B2_ABL & 4)) ? (unsigned)(((n * 28 + y) * 28 + x) * 128 + (slot ^ (cc & 7)) * 8) * 2u : kOobOffset;
             }
         };
         auto issue_band = [&](int c2) {           // 9 DMAs per wave: chunk c2 of the band decoded last
@@ -3052,7 +3053,7 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
 
         auto run = [&](auto nrw_c, auto nq_c) {
             constexpr int NRW = decltype(nrw_c)::value, NQ = decltype(nq_c)::value;
-            f32x4 acc[2][NRW], accA[2][NQ];
+            f32x4 acc[2][NRW], accA[2][NQ], accC[2][7];        // accC: conv2 (7 slot blocks in either half); dead once t2 is in LDS
             int cbuf = 0;
             // acc[m][j] += W[rows 16 m + fr of `wb`][64 K] . X[64 K][pixel block j]; `xaddr(t)` = address of the fragment of slot t = NB kk + j
             auto gemm64 = [&](auto nb_c, const char* wb, auto xaddr, auto& ac) {
@@ -3102,44 +3103,46 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
 #pragma unroll 1
             for (int tile = first; tile < a.n_tiles; tile += grid) {
                 const unsigned tile_pix0 = (unsigned)((tile >> 2) * 784 + (tile & 3) * NPX);
-                // ---- conv2: bias, then 18 stages against the resident band
+                // ---- conv2: bias, then 18 stages against the resident band (row blocks: slot 16 b + fr of block b = 7 wave_p + j is output
+                //      row b >> 1, column 16 (b & 1) + fr; columns 28..31 are unused slots)
                 {
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (ch_lane) * 4);
                     const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (ch_lane + 4) * 4);
 #pragma unroll
-                    for (int j = 0; j < NRW; ++j) { acc[0][j] = lo; acc[1][j] = hi; }
+                    for (int j = 0; j < 7; ++j) { accC[0][j] = lo; accC[1][j] = hi; }
                 }
+                // lane constants of the fragment addresses, recomputed per tile (an opaque zero keeps them out of the registers that live
+                // across the whole tile loop: the chained tail needs those)
+                int opq = 0;
+                asm volatile("" : "+v"(opq));
                 {
-                    // padded position of this lane's pixel of block j at tap (0,0); recomputed per tile (an opaque zero keeps the seven
-                    // values out of the registers that live across the whole tile loop: the chained tail needs them)
-                    int opq = 0;
-                    asm volatile("" : "+v"(opq));
-                    int q0[NRW];
+                    int vb[3][2];                                       // [tap column][K half]: position fr + kw, chunk (fq + 4 kk) ^ key
 #pragma unroll
-                    for (int j = 0; j < NRW; ++j) {
-                        const int p = p0 + 16 * j + opq;
-                        const int pc = p < NPX ? p : NPX - 1;
-                        const int r = pc / IW, c = pc - r * IW;
-                        q0[j] = r * PW + c;
-                    }
+                    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) vb[kw][kk] = (fr + kw + opq) * 128 + (((fq + 4 * kk) ^ ((fr + kw) & 7)) << 4);
 #pragma unroll 1
                     for (int c2 = 0; c2 < 2; ++c2) {
-                        const char* xb = smem + XB_OFF + c2 * XBUF;
-#pragma unroll 1
+                        const char* const xc = smem + XB_OFF + c2 * XBUF + 7 * 2048 * wave_p;
+#pragma unroll
                         for (int tap = 0; tap < 9; ++tap) {
-                            const int kh = (tap >= 6) ? 2 : (tap >= 3) ? 1 : 0, kw = tap - 3 * kh;
-                            const int sw = (kh * PW + kw) * 128 + ((fq ^ ((p0 + kh * IW + kw) & 7)) << 4);      // tap offset + the tap's chunk key
-                            gemm64(NRWc, smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) {
-                                return xb + q0[t % NRW] * 128 + (t >= NRW ? (sw ^ 64) : sw);
-                            }, acc);
+                            const int kh = tap / 3, kw = tap - 3 * kh;
+                            const char* const x0 = xc + vb[kw][0] + kh * (PW * 128);
+                            const char* const x1 = xc + vb[kw][1] + kh * (PW * 128);
+                            gemm64(std::integral_constant<int, 7>{}, smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) {
+                                return (t >= 7 ? x1 : x0) + (t % 7) * 2048;
+                            }, accC);
                             stage_done();
                         }
                     }
                 }
-                // ---- t2 = relu(acc) -> T2 (everybody is past the last conv2 stage's barrier: the band is dead)
+                // ---- t2 = relu(accC) -> T2, compact pixel rows p = 28 r + column (everybody is past the last conv2 stage's barrier: the band is dead)
 #pragma unroll
-                for (int j = 0; j < NRW; ++j)
-                    *reinterpret_cast<u32x4*>(smem + T2_OFF + cf_a + ((pb0 + 2048 * j) ^ cf_x)) = pack_relu(acc[0][j], acc[1][j]);
+                for (int j = 0; j < 7; ++j) {
+                    const int b = 7 * wave_p + j;
+                    const int col = 16 * (b & 1) + fr, p = 28 * (b >> 1) + col + opq;
+                    if (col < IW) *reinterpret_cast<u32x4*>(smem + T2_OFF + cf_a + ((p * 128 + ((fq ^ (p & 7)) << 4)) ^ cf_x)) = pack_relu(accC[0][j], accC[1][j]);
+                }
                 if constexpr (C1N != 0) {         // the next conv1's accumulators take over conv2's registers
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (640 + ch_lane) * 4);
                     const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (640 + ch_lane + 4) * 4);

@@ -1,6 +1,7 @@
 #!/bin/bash
 # End-of-round refresh on the GPU box: full GPU test suite, default bench line, rocprofv3 kernel stats of the same command, per-layer
-# profile, PMC passes (HBM bytes, MFMA utilisation).  Outputs under gpurun_out/; copy the summaries into profiles/.
+# profile, PMC passes (HBM bytes per launch with the per-launch table, MFMA utilisation; full-batch launches only).  Outputs under
+# gpurun_out/; copy the summaries into profiles/ (r03_* names in profiles/README.md).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout -k 10 900 python3 -m pytest tests -m gpu -q > gpurun_out/t_final.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/t_final.log
@@ -8,12 +9,9 @@ timeout -k 10 300 python3 bench.py > gpurun_out/bench_final.json 2> gpurun_out/b
 rm -rf gpurun_out/prof_final
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --preheat 0.3 > gpurun_out/prof_final.log 2>&1 || echo "rocprof stats failed"
 timeout -k 10 200 python3 scripts/layer_profile.py > gpurun_out/layer_profile_final.txt 2>&1 || echo "layer profile failed"
-rm -rf gpurun_out/pmcb_FETCH_SIZE gpurun_out/pmcb_WRITE_SIZE
 bash scripts/pmc_bench.sh
-python3 scripts/pmc_bench_summary.py > gpurun_out/pmc_hbm_traffic_final.json
 bash scripts/pmc_bench_mfma.sh
 f=$(ls -t gpurun_out/prof_final/*/*kernel_trace.csv | head -1); python3 scripts/kernel_gaps.py $f > gpurun_out/kernel_gaps_final.txt 2>&1
+f=$(ls -t gpurun_out/prof_final/*/*kernel_stats.csv | head -1); cp $f gpurun_out/kernel_stats_final.csv
 timeout -k 10 100 python3 scripts/hbm_copy_probe.py > gpurun_out/hbm_copy_probe.txt 2>&1
-R50_LIB=$PWD/implementation_phd_lab_vision_amd/libr50hip_stamp.so timeout -k 10 100 python3 scripts/stamp_tail3.py 256 > gpurun_out/stamps_tail3.txt 2>&1
-R50_LIB=$PWD/implementation_phd_lab_vision_amd/libr50hip_stamp.so timeout -k 10 100 python3 scripts/stamp_xres.py 14 256 > gpurun_out/stamps_xres.txt 2>&1
 tail -3 gpurun_out/t_final.log; cut -c1-300 gpurun_out/bench_final.json
