@@ -1031,6 +1031,9 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
 #ifndef XRES_ABL
 #define XRES_ABL 0
 #endif
+#ifndef XRES_STATIC_LOADER    // row-block form: 1 = the unrolled static loader schedule, 0 = the dynamic loader loop (A/B: scripts/build_variant.sh -DXRES_STATIC_LOADER=0)
+#define XRES_STATIC_LOADER 1
+#endif
 #ifndef XRES_PD           // row-block schedule: pixel fragments read ahead of their MFMAs
 #define XRES_PD 3
 #endif
@@ -1137,6 +1140,66 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
                 if (XRES_ABL & 32) x_voff[i] = kOobOffset;
             }
         };
+        if constexpr (RB == 1 && NST == 3 && XRES_STATIC_LOADER) {
+            // ---- STATIC loader schedule (round 3): the nine iterations of a chunk are unrolled, every iteration issues its weight stage (stage
+            // g + 2) and ONE pass of the next chunk's input (two at iteration 0 when the buffer has nine passes) with compile-time pass indices,
+            // and waits with one scalar compare.  The dynamic loop below spends ~85 scalar instructions and ~20 branches per iteration on the same
+            // decisions; beside two consumer waves per SIMD that is time in which its DMAs are not being issued.
+            // Hazards as the dynamic loop: a pass issued at iteration i (behind barrier i - 1, i.e. after every step of the chunk before this one)
+            // is confirmed by the wait of iteration i + 1 and read from the next chunk's step 0 = iteration 9 on; last pass at iteration 7.
+            int w_tile = first, w_c = 0, w_s = 0, w_buf = 0;
+            auto w_stage = [&]() {
+                const int wofs = __builtin_amdgcn_readfirstlane((w_s * a.Cin + w_c * 64) * 2);
+                char* sbase = smem + WRING + w_buf * WSTAGE + lw * 1024;
+#pragma unroll
+                for (int i = 0; i < WPASS; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LDS_AS void*)(sbase + i * 4096), 16, w_voff[i], wofs, 0, 0);
+                w_buf = (w_buf == 2) ? 0 : w_buf + 1;
+                if (++w_s == 9) {
+                    w_s = 0;
+                    if (++w_c == cch) { w_c = 0; w_tile += grid; if (w_tile < n_tiles) decode_w(w_tile); }
+                }
+            };
+            int x_par = 0;
+            auto x_one = [&](int pass, int chunk) {                  // pass: compile-time after unrolling
+                const int xofs = __builtin_amdgcn_readfirstlane(chunk * 128);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + x_par * XBUF + pass * 4096 + lw * 1024), 16, x_voff[pass], xofs, 0, 0);
+            };
+            decode_w(first);
+            decode_x(first);
+#pragma unroll
+            for (int p = 0; p < XPASS; ++p) x_one(p, 0);
+            w_stage();
+            w_stage();                                                // total >= 9
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPASS) : "memory");          // the first chunk's input and stage 0 landed
+            __builtin_amdgcn_s_barrier();
+            int t_cur = first, c_cur = 0;
+            for (int g = 0; g < total; g += 9) {
+                int t_nxt = t_cur, c_nxt = c_cur + 1;
+                if (c_nxt == cch) { c_nxt = 0; t_nxt += grid; }
+                const bool has_nxt = t_nxt < n_tiles;
+                x_par ^= 1;                                           // the buffer the NEXT chunk goes into
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const bool w_ok = g + i + 2 < total;
+                    if (w_ok) w_stage();
+                    constexpr int EXTRA = XPASS - 8;                  // 0 or 1
+                    if (has_nxt) {
+                        if (i == 0) {
+                            if (t_nxt != t_cur) decode_x(t_nxt);
+                            x_one(0, c_nxt);
+                            if constexpr (EXTRA) x_one(1, c_nxt);
+                        } else if (i < 8) {
+                            x_one(i + EXTRA, c_nxt);
+                        }
+                    }
+                    const int nx = has_nxt ? (i == 0 ? 1 + EXTRA : (i < 8 ? 1 : 0)) : 0;
+                    if (w_ok && nx == 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPASS + 1) : "memory"); }
+                    else wait_vmcnt((w_ok ? WPASS : 0) + nx);        // everything issued before this iteration has landed
+                    __builtin_amdgcn_s_barrier();
+                }
+                t_cur = t_nxt; c_cur = c_nxt;
+            }
+        } else {
         // stream position of the NEXT step to issue, and of the input chunk that is fetched beside it (one chunk ahead)
         int i_tile = first, i_c = 0, i_s = 0, i_buf = 0;
         int x_tile = first, x_c = 0, x_par = 0;                       // chunk being fetched: tile, chunk, buffer
@@ -1222,6 +1285,7 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
             R50_MARK(2)                           // barrier
         }
         R50_STAMP_FLUSH(12)
+        }
     } else if constexpr (RB == 3) {
         // =============================== consumer waves, 32-wide blocks ==============================
         constexpr int NBK = 7, NS = 4 * NBK, PD = XRES_PD + 1;            // 7 blocks of 32 slots; slot t = 7 ks + b of a step; fragments read ahead
