@@ -2912,6 +2912,14 @@ struct Block2Args {
 #ifndef B2_ABL
 #define B2_ABL 0
 #endif
+#ifndef B2_LOADER_UNROLL      // 1 = the loaders' position loop fully unrolled; 0 = rolled (A/B: scripts/build_variant.sh -DB2_LOADER_UNROLL=0)
+#define B2_LOADER_UNROLL 1
+#endif
+#if B2_LOADER_UNROLL
+#define B2_LOADER_LOOP _Pragma("unroll")
+#else
+#define B2_LOADER_LOOP _Pragma("unroll 1")
+#endif
 template <int ET, int C1N>
 __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -3061,7 +3069,10 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
         for (int tile = first; tile < a.n_tiles; tile += grid) {
             const bool has_next = tile + grid < a.n_tiles;
             const unsigned tile_pix0 = (unsigned)((tile >> 2) * 784 + (tile & 3) * NPX);
-#pragma unroll 1
+            // (round 3) the position loop is UNROLLED: with p a constant, every decision below -- which DMAs this iteration carries, their scalar
+            // offsets, the vmcnt to wait for -- folds at compile time; rolled, the loaders spent a few hundred cycles of scalar compares and
+            // branches per barrier interval on them, in the phase (A / E / B) where the loaders pace the kernel
+            B2_LOADER_LOOP
             for (int p = 0; p < SPT; ++p) {
                 // the consumers' extra barriers: T2 complete (in front of stage 18), OUTC(c) complete (in front of every B stage)
                 if (p == NCONV || (C1N && p > NCONV && ((p - NCONV) & 1) == 1)) __builtin_amdgcn_s_barrier();
@@ -3458,7 +3469,7 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
         for (int tile = first; tile < a.n_tiles; tile += grid) {
             const bool has_next = tile + grid < a.n_tiles;
             const unsigned tile_pix0 = (unsigned)((tile / 14) * 3136 + (tile % 14) * NPX);
-#pragma unroll 1
+            B2_LOADER_LOOP                                            // (round 3: unrolled, as bneck_block2_kernel's)
             for (int p = 0; p < SPT; ++p) {
                 const int q = p - NCONV, c = q >= 0 ? q / LCH : -1, r = q >= 0 ? q - c * LCH : -1;
                 // the consumers' extra barriers: T2 complete (in front of the first A stage), OUTC(c) complete (in front of the first B stage)
