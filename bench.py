@@ -202,7 +202,7 @@ def main() -> None:
     ap.add_argument("--no-ds-cat", action="store_true", help="A/B: downsample conv and conv3 of layer2.0 / 3.0 / 4.0 as separate launches")
     ap.add_argument("--no-overlap-ds", action="store_true", help="A/B: downsample convs on the main stream")
     ap.add_argument("--no-block2", action="store_true", help="A/B: layer2.1-.3 as conv2 launch + fused tail instead of one launch per bottleneck body")
-    ap.add_argument("--block1", type=int, default=-1, help="A/B: option fuse_block1 (0 = layer1 as conv2 launch + fused tail, 1 = layer1.1 in one launch, 2 = layer1.2 too)")
+    ap.add_argument("--block1", type=int, default=-1, help="A/B: option fuse_block1 (0 = layer1 as conv2 launch + fused tail, 1 = layer1.1 in one launch, 2 = layer1.2 too: the default)")
     ap.add_argument("--inplace", action="store_true", help="A/B: plain-identity blocks write their output over their input (same bits; measured: no gain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true",
@@ -442,7 +442,7 @@ def main() -> None:
                 b_traffic = tdata["bneck_block"]["hbm_bytes_per_launch"]
             except Exception:
                 pass
-            roofline["fourth_kernel"] = {"kernel": "bneck_block1_kernel / bneck_block2_kernel (%d launches/step: layer1.1, layer2.1-.3)" % round(b2["launches"] / max(1, args.steps)),
+            roofline["fourth_kernel"] = {"kernel": "bneck_block1_kernel / bneck_block2_kernel (%d launches/step: layer1.1-.2, layer2.1-.3)" % round(b2["launches"] / max(1, args.steps)),
                                          "traffic": b_traffic, "traffic_source": traffic_source, "algorithmic_bytes": b2["bytes"] / max(1, b2["launches"]),
                                          "avg_launch_us": 1e3 * b2["ms"] / max(1, b2["launches"]),
                                          "tflops": b2["flops"] / (b2["ms"] * 1e-3) / 1e12, "frac_of_mfma_peak": b2["flops"] / (b2["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,

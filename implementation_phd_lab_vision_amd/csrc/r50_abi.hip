@@ -69,7 +69,8 @@ struct r50_handle {
     int fuse_fp8_handover = 1;          // fp8 mode: quantise layer1's output in layer1.2.conv3's epilogue instead of in a pass of its own
     int fuse_tail3 = 1;                 // layer3.1-.4: conv3 + identity + ReLU chained with the next block's conv1 through LDS (bneck_tail3_kernel)
     __bf16* tail3_wp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per layer3 block b: [W3(b) | W1(b+1)] in the kernel's fragment order
-    int fuse_block1 = 1;                // layer1.1 (2: also layer1.2): the bottleneck body in one launch (bneck_block1_kernel)
+    int fuse_block1 = 2;                // 1: layer1.1, 2 (default since round 3: with the loaders' position loop unrolled the c1 = 128 form takes 248 us against
+                                        // 276 for conv2 + fused tail): also layer1.2 -- the bottleneck body in one launch (bneck_block1_kernel)
     int fuse_block2 = 1;                // layer2.1-.3: the whole bottleneck body (conv2 + conv3 + identity + ReLU [+ next conv1]) in one launch
     int inplace_out = 0;                // plain-identity blocks write their output over their input (same bits, fewer DRAM page switches)
     int n_streams = 1;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)

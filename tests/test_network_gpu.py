@@ -225,16 +225,16 @@ def test_fused_stem_equals_unfused(setup):
 def test_default_fusions_give_the_bits_of_plain_launches(lib_built, precision):
     """With the bottleneck bodies of layer1.1 / layer2.1-.3 in one launch each (bneck_block1 / bneck_block2), the layer1 tails and the
     chained layer3 tails, EVERY fusion on the default path reproduces the summation order of the launches it replaces: the features
-    are the same bits as with one igemm launch per conv (`fuse_tail` = 0 turns all of them off).  Also with layer1.2 as one launch."""
+    are the same bits as with one igemm launch per conv (`fuse_tail` = 0 turns all of them off).  Also with layer1.2 as two launches."""
     from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
     from implementation_phd_lab_vision_amd.weights import synthetic_frames
     x = synthetic_frames(5, seed=77).to("cuda:0")
     bb = ResNet50Backbone(seed=0, max_batch=5, precision=precision).to("cuda:0").eval()
     try:
-        assert bb.get_option("fuse_block1") == 1 and bb.get_option("fuse_block2") == 1
+        assert bb.get_option("fuse_block1") == 2 and bb.get_option("fuse_block2") == 1      # round 3: layer1.2 is one launch by default too
         f_default = bb.features(x).clone()
-        bb.set_option("fuse_block1", 2)
-        f_b12 = bb.features(x).clone()
+        bb.set_option("fuse_block1", 1)
+        f_b12 = bb.features(x).clone()                                                   # the round-2 default (layer1.2 as conv2 + fused tail)
         bb.set_option("fuse_block1", 0); bb.set_option("fuse_block2", 0)
         f_tails = bb.features(x).clone()          # layer2 through bneck_tail2_kernel: its next conv1 sums K in eight slices
         bb.set_option("fuse_tail", 0)
