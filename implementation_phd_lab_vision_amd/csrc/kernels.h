@@ -610,6 +610,13 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
                 for (int i = 0; i < XROWS; ++i)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x2, (LDS_AS void*)(sbase + BC * 128 + i * PASS_BYTES + lw * 1024), 16,
                                                              x2_voff[i], x2ofs, 0, 0);
+            } else if (a.ks == 1) {
+                // 1x1 conv (round 3): a row's offset is either valid for the whole K loop or out of range (decode_tile), so the per-tap padding mask --
+                // four vector-ALU instructions per DMA, ~0.5 per MFMA of the kernel, issued on the SIMDs the consumers' MFMAs issue on -- is skipped
+#pragma unroll
+                for (int i = 0; i < XROWS; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void*)(sbase + BC * 128 + i * PASS_BYTES + lw * 1024), 16,
+                                                             x_voff[i], xofs, 0, 0);
             } else {
 #pragma unroll
             for (int i = 0; i < XROWS; ++i) {
