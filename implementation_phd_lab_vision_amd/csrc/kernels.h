@@ -2629,14 +2629,21 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
             for (int i = 0; i < 14; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y2, (LDS_AS void*)(smem + T2 + i * 4096 + lw * 1024), 16, row_voff(i, p0, limit, CMID), 0, 0, 0);
         };
-        auto issue_res = [&](int tile, int c) {   // 7 DMAs per wave: residual rows of chunk c (2 K-slots) into buffer c & 1
+        // (round 3) the 7 row offsets of the identity rows / block-output rows of a tile are computed ONCE per tile (this tile's and the next one's)
+        // instead of per DMA and per store: ~110 vector-ALU instructions per chunk and helper wave less on the SIMDs the consumers' MFMAs issue on
+        unsigned rv_cur[7], rv_nxt[7];
+        auto tile_rows = [&](int tile, unsigned (&rv)[7]) {
             const int p0 = tile * a.bp;
             const int limit = (tile < a.n_tiles) ? ((a.M - p0 < a.bp) ? a.M - p0 : a.bp) : 0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) rv[i] = row_voff(i, p0, limit, COUT);
+        };
+        auto issue_res = [&](const unsigned (&rv)[7], int c) {   // 7 DMAs per wave: residual rows of chunk c (2 K-slots) into buffer c & 1
             const int cofs = __builtin_amdgcn_readfirstlane(c * 256);
             char* dst = smem + RES + (c & 1) * 2 * SLOT + lw * 1024;
 #pragma unroll
             for (int i = 0; i < 7; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(dst + i * 4096), 16, row_voff(i, p0, limit, COUT), cofs, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(dst + i * 4096), 16, rv[i], cofs, 0, 0);
         };
         auto copy_out = [&](int tile, int c) {    // 7 x (16 B from out_c -> block output): full 128-B row pieces
             const int p0 = tile * a.bp;
@@ -2647,7 +2654,7 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
             for (int i = 0; i < 7; ++i) v[i] = *reinterpret_cast<const u32x4*>(smem + OUTC + i * 4096 + lt * 16);
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-                unsigned voff = row_voff(i, p0, limit, COUT);
+                unsigned voff = rv_cur[i];
                 if (T3_ABL & 1) {                  // (ablation 1 makes row_voff out of range: rebuild the store offset)
                     const int R = 32 * i + srow, sl = (R >= 112) ? 1 : 0, prow = R - 112 * sl;
                     voff = (prow < limit) ? (unsigned)((p0 + prow) * COUT + sl * 64 + (((lt & 7) ^ (prow & 7)) * 8)) * 2u : kOobOffset;
@@ -2658,9 +2665,10 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
         // Every wave's vector-memory queue holds, in issue order:  ... Res(t,0) | stores(6) | T2(t) | Res(t,1) | stores(7) |   <- previous tile
         //    Res(t,2) | stores(0) | Res(t,3) | stores(1) | ...   with 7 / 14 operations per group (requests for tiles past the end are
         // issued too, as zero fills, so the counts never change).  The first tile has no stores in front: prologue = Res(0) | T2 | Res(1).
-        issue_res(first, 0);
+        tile_rows(first, rv_cur);
+        issue_res(rv_cur, 0);
         issue_t2(first);
-        issue_res(first, 1);
+        issue_res(rv_cur, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();             // biases staged (pairs with the consumers' first barrier)
         bool first_tile = true;
@@ -2669,6 +2677,8 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
             // T: t2 rows landed.  Younger than T2(t): Res(t,1) [+ stores(7)]
             if (first_tile) { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
             __builtin_amdgcn_s_barrier();
+            tile_rows(tile + grid, rv_nxt);
+#pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 // R(c): residual(c) landed.  Younger than Res(t,c): see the queue above
                 if (c == 0) {
@@ -2684,13 +2694,15 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
                 if (c == NCH - 1) issue_t2(tile + grid);        // every consumer is past A(7): the T2 region is free
                 __builtin_amdgcn_s_barrier();     // O(c): out_c(c) complete, res buffer c & 1 free
                 R50_MARK(2)                       // (t2 issue +) barrier O
-                if (c + 2 < NCH) issue_res(tile, c + 2); else issue_res(tile + grid, c + 2 - NCH);
+                if (c + 2 < NCH) issue_res(rv_cur, c + 2); else issue_res(rv_nxt, c + 2 - NCH);
                 R50_MARK(3)                       // residual DMA issue
                 copy_out(tile, c);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the copy's LDS reads are complete before this wave arrives at R(c+1))
                 R50_MARK(4)                       // copy-out: LDS reads + store issue
             }
             first_tile = false;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) rv_cur[i] = rv_nxt[i];
         }
         R50_STAMP_FLUSH(8)
     } else {
