@@ -2022,7 +2022,11 @@ __global__ __launch_bounds__(768) void conv3x3_s2_kernel(const ConvArgs a) {
                 }
                 if (i == 7 && has_nxt) { x_pass(0, 4, c_nxt); x_pass(0, 5, c_nxt); x_pass(0, 6, c_nxt); x_pass(0, 7, c_nxt); next_buf(); ops += 4; }
                 if (i == 8 && has_nxt) { x_pass(1, 0, c_nxt); x_pass(1, 1, c_nxt); ops += 2; }
-                wait_vmcnt(ops);                  // everything issued before this iteration has landed: step g + i + 1's stage and planes
+                // everything issued before this iteration has landed (step g + i + 1's stage and planes): all but this iteration's `ops`.  In the steady
+                // state `ops` is the table's figure for iteration i: one scalar compare instead of wait_vmcnt's six
+                constexpr int QF[9] = {4, 4, 4, 2, 3, 3, 6, 4, 2};
+                if (ops == WPASS + QF[i]) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPASS + QF[i]) : "memory"); }
+                else wait_vmcnt(ops);
                 __builtin_amdgcn_s_barrier();
             }
             t_cur = t_nxt; c_cur = c_nxt;
