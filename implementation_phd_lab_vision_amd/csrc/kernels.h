@@ -2775,6 +2775,9 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
                 if (t == NR - 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            // a scheduling region per step: without this fence the scheduler fills a step's "2 MFMAs" groups with MFMAs of LATER steps (same
+            // accumulator chain), which then wait with vmcnt(0) for weight fragments requested a moment ago (seen in the ISA: vmcnt 5, 4, .. 0)
+            __builtin_amdgcn_sched_barrier(0);
         };
         w_load(0, wA);
         w_load(1, wB);
@@ -2877,6 +2880,346 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
                 }
             R50_MARK(6)                           // y1n epilogue
         }
+        R50_STAMP_FLUSH(8)
+    }
+#else
+    (void)a;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// bneck_tail3p_kernel (round 3): the chained layer3 tail of bneck_tail3_kernel as a TWO-GROUP PIPELINE.
+// What the stamps of bneck_tail3_kernel said (profiles/r02_stamps_bneck_tail3.txt): its four consumer waves -- one per SIMD -- spend
+// 48 % of their cycles issuing MFMAs; the rest is the serial A -> R -> E -> O -> B chain of one wave (LDS round trips at every step's
+// head, the epilogue's vector work, two barriers per chunk), and nothing else on the SIMD has MFMAs to fill those holes with.
+// Here the two GEMMs of a chunk run on DIFFERENT waves, one chunk apart, so every SIMD always holds two MFMA-issuing waves in
+// different phases:
+//   * group A, waves 0-3 (wave w: couts 32w.. of the chunk's 128, all 7 pixel blocks): accA = b3 + W3[c] . t2 (4 weight steps, t2
+//     resident in LDS), then E(c): + identity, ReLU, 16 bit -> LDS out_c[c & 1].  The identity does not go through LDS at all: lane
+//     (fr, fq) needs exactly 16 B of it per pixel block (its own 8 channels of its own pixel), so it is loaded straight into
+//     registers, one chunk ahead (the load of chunk c + 1, block j, is issued the moment block j of chunk c has been consumed).
+//     Group A also DMAs the next tile's t2 rows.
+//   * group B, waves 4-7 (wave w: couts 32w.. of each 128-row half, all 7 pixel blocks), one chunk BEHIND: accB += W1[:, c] . out_c
+//     (4 weight steps), then the copy-out of out_c to the block output with full-row stores; y1n = relu(accB) after chunk 7.
+//   * ONE barrier per chunk: out_c[c & 1] complete / out_c[(c - 1) & 1] consumed.  A tile takes nine intervals (A idles in the last one,
+//     where the next tile's t2 rows land; B idles in the first one, where it stores the previous tile's y1n).
+// Weights: the fragment-ordered stream of tail3_pack_kernel, fetched two steps ahead into registers by the wave that uses them
+// (steps 0-3 of a chunk by group A, 4-7 by group B).  Summation orders are unchanged: both outputs keep the bits of bneck_tail3_kernel
+// and of the two igemm launches.
+// LDS: T2 [4 slots][ROWS] + out_c 2 x [2 slots][ROWS] rows of 128 B + b1 + b3 = 119,808 B at ROWS = 112.
+// ------------------------------------------------------------------------------------------------
+#ifndef T3P_ABL           // diagnostic ablations (timing only): 1 = no identity loads, 2 = no HBM stores, 4 = no MFMAs, 8 = no E work, 16 = no pixel-fragment LDS reads, 32 = no weight loads
+#define T3P_ABL 0
+#endif
+#ifndef T3P_XPRE          // cross-step prefetch of the first pixel fragments of the next step (1 = group A, 2 = group B): measured neutral
+#define T3P_XPRE 0
+#endif
+#ifndef T3P_COPY          // who writes the block output: 0 = group A straight from its E-phase registers (64-B pieces), 1 = group B copies out_c out of LDS (full rows)
+#define T3P_COPY 0
+#endif
+#ifndef T3P_PRIO          // wave priority: 1 = group B at s_setprio 1, 2 = group A at s_setprio 1, 4 = group A at s_setprio 2 during its E phase
+#define T3P_PRIO 0
+#endif
+#ifndef T3P_PDA           // LDS prefetch depth (pixel fragments) of the A / B weight steps
+#define T3P_PDA 6
+#endif
+#ifndef T3P_PDB
+#define T3P_PDB 6
+#endif
+template <int ET, int ROWS>
+__global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int CMID = 256, COUT = 1024, C1N = 256;
+    constexpr int NCH = COUT / 128;               // chunks of 128 block-output channels
+    constexpr int NR = 7;                         // MFMA column blocks (pixel rows 16 j + fr; rows >= ROWS are never stored)
+    constexpr int SLOT = ROWS * 128;              // one K-slot (64 channels) of ROWS pixel rows
+    constexpr int T2 = 0, OUTC = 4 * SLOT, B1_OFF = OUTC + 4 * SLOT, B3_OFF = B1_OFF + C1N * 4;
+    constexpr int T2_PASSES = (4 * ROWS + 31) / 32, OC_PASSES = (2 * ROWS + 31) / 32;      // 32-row passes of 256 lanes x 16 B
+    static_assert(ROWS == 112 || ROWS == 98, "row counts with a whole number of 8-row DMA pieces per region");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wave & 3;
+    const int lt = tid & 255, srow = lt >> 3;
+    const int grid = gridDim.x;
+    const int first = blockIdx.x;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    if (tid < C1N) {                              // both bias vectors live in LDS
+        reinterpret_cast<float*>(smem + B1_OFF)[tid] = a.b1[tid];
+        reinterpret_cast<f32x4*>(smem + B3_OFF)[tid] = reinterpret_cast<const f32x4*>(a.b3)[tid];
+    }
+
+    const __amdgpu_buffer_rsrc_t rs_wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wp), 0, 1048576u, 0x00020000);
+    const unsigned wp_voff = (unsigned)(lane * 16 + w * 4096);
+    const int fphys0 = (fq ^ (fr & 7)) << 4;                       // kk = 0; kk = 1 is ^ 64
+    const int x_frag = fr * 128;                                    // + j * 2048
+    // weight fragments of step g of the group's own sequence (4 steps per chunk; GOFS = 0: W3 steps, 4: W1 steps), K half kk
+    auto w_load_half = [&](int g, int gofs, bf16x8 (&wf)[4], int kk) {
+        const int sofs = __builtin_amdgcn_readfirstlane((((((g >> 2) & 7) << 3) + (g & 3) + gofs)) << 14);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if constexpr (T3P_ABL & 32) wf[2 * m + kk] = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)sofs, 1u, 2u, 3u});
+            else wf[2 * m + kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wp, wp_voff + (2 * m + kk) * 1024, sofs, 0));
+        }
+    };
+    // one weight step: acc[m][j] += W[32w + 16m ..][64 K] . X[64 K][16 j ..]; 14 slots t = 7 kk + j of one pixel fragment and two MFMAs, the
+    // fragment of slot t + PD read when slot t issues; the K half a step has finished with is re-requested for step g + 2 at once.
+    // Steps are separate scheduling regions (see bneck_tail3_kernel's w_step), so a step would open with an exposed LDS round trip; where the
+    // NEXT step's operand is already complete in LDS (HAVE / NXT: inside a chunk), its first PD fragments are requested in this step's last
+    // slots, which have no reads of their own left, and handed over in `xq`.
+    auto w_step = [&](auto pd, auto wd_c, auto have_c, auto nxt_c, int g, int gofs, bf16x8 (&wf)[4], const char* xb, const char* xnb, f32x4 (&acc0)[NR],
+                      f32x4 (&acc1)[NR], bf16x8 (&xq)[NR]) {
+        constexpr int NS = 2 * NR, PD = decltype(pd)::value, WD = decltype(wd_c)::value;      // WD: the buffer is re-requested for step g + WD
+        constexpr bool HAVE = decltype(have_c)::value, NXT = decltype(nxt_c)::value;
+        bf16x8 x[NS];
+        auto xread = [&](const char* b, int t) {
+            if constexpr (T3P_ABL & 16) return __builtin_bit_cast(bf16x8, (u32x4){(unsigned)(size_t)b, (unsigned)t, 2u, 3u});
+            else return *reinterpret_cast<const bf16x8*>(b + x_frag + (t % NR) * 2048 + (t >= NR ? (fphys0 ^ 64) : fphys0));
+        };
+#pragma unroll
+        for (int t = 0; t < PD; ++t) x[t] = HAVE ? xq[t] : xread(xb, t);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int j = t % NR, kk = t / NR;
+            if constexpr (T3P_ABL & 4) { asm volatile("" ::"v"(wf[kk]), "v"(wf[2 + kk]), "v"(x[t])); }
+            else {
+                acc0[j] = mfma_e<ET>(wf[kk], x[t], acc0[j]);
+                acc1[j] = mfma_e<ET>(wf[2 + kk], x[t], acc1[j]);
+            }
+            if (t + PD < NS) x[t + PD] = xread(xb, t + PD);
+            else if (NXT) xq[t + PD - NS] = xread(xnb, t + PD - NS);
+            if (t == NR - 1) w_load_half(g + WD, gofs, wf, 0);
+        }
+        w_load_half(g + WD, gofs, wf, 1);
+        if (!HAVE) __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (t + PD < NS || NXT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (t == NR - 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);        // a scheduling region per step
+    };
+    bf16x8 wA[4], wB[4], xq[NR];
+    using YES = std::true_type;
+    using NO = std::false_type;
+
+    if (wave < 4) {
+        // =============================== group A: conv3 + identity + ReLU -> out_c ===================
+        const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.y2), 0, (unsigned)a.M * (CMID * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.M * (COUT * 2u), 0x00020000);
+        // the tile's t2 rows: row R = 32 i + srow of the [4 slots][ROWS] region -> K-slot R / ROWS, pixel row R % ROWS, logical 16-B chunk
+        // (lane & 7) ^ (pixel row & 7); rows past the tile's real pixels zero-fill (out-of-range offset)
+        auto issue_t2 = [&](int tile) {
+            const int p0 = tile * a.bp;
+            const int limit = (tile < a.n_tiles) ? ((a.M - p0 < a.bp) ? a.M - p0 : a.bp) : 0;
+#pragma unroll
+            for (int i = 0; i < T2_PASSES; ++i) {
+                const int R = 32 * i + srow;
+                const int sl = R / ROWS, prow = R - ROWS * sl;
+                const int lchunk = (lt & 7) ^ (prow & 7);
+                const unsigned voff = (prow < limit) ? (unsigned)((p0 + prow) * CMID + sl * 64 + lchunk * 8) * 2u : kOobOffset;
+                if (32 * i + 32 <= 4 * ROWS || w == 0)      // (ROWS = 98: the last pass is the 8 rows of wave 0)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y2, (LDS_AS void*)(smem + T2 + i * 4096 + w * 1024), 16, voff, 0, 0, 0);
+            }
+        };
+        // the lane's identity values / block-output values: pixel row 16 j + fr, channels (chunk) + 32 w + 8 fq .. + 7 (same offsets in both tensors)
+        unsigned rv[NR], rvn[NR];                 // this tile's and the next tile's
+        auto tile_rows = [&](int tile, unsigned (&v)[NR]) {
+            const int p0 = tile * a.bp;
+            const int limit = (tile < a.n_tiles) ? ((a.M - p0 < a.bp) ? a.M - p0 : a.bp) : 0;
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+                v[j] = (16 * j + fr < limit) ? (unsigned)((p0 + 16 * j + fr) * COUT + 32 * w + 8 * fq) * 2u : kOobOffset;
+        };
+        const int c_frag = (w >> 1) * SLOT + x_frag + (((4 * (w & 1) + fq) ^ (fr & 7)) << 4);
+        f32x4 accA[2][NR];
+        // Group A's VM queue carries the identity loads and the block-output stores -- HBM latencies, and vmcnt counts in issue order.  So
+        //   * the identity is requested TWO chunks ahead (two register sets, even / odd chunks; 28 KB in flight per CU per chunk were what
+        //     paced the first version: with no MFMAs at all it took the same 80 us), inside E before that E's stores;
+        //   * the weight fragments are requested FOUR steps (one chunk) ahead instead of two: a wait for them then covers nothing younger
+        //     than the previous chunk's E phase.
+        u32x4 r0[NR], r1[NR];
+        bf16x8 wq[4][4];
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.M * (COUT * 2u), 0x00020000);
+        tile_rows(first, rv);
+        tile_rows(first + grid, rvn);
+        issue_t2(first);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) r0[j] = (T3P_ABL & 1) ? (u32x4){0u, 0u, 0u, 0u} : __builtin_amdgcn_raw_buffer_load_b128(rs_res, rv[j], 0, 0);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) r1[j] = (T3P_ABL & 1) ? (u32x4){0u, 0u, 0u, 0u} : __builtin_amdgcn_raw_buffer_load_b128(rs_res, rv[j], 256, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { w_load_half(q, 0, wq[q], 0); w_load_half(q, 0, wq[q], 1); }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // own t2 pieces landed, own bias words written
+        __builtin_amdgcn_s_barrier();             // P
+        if (T3P_PRIO & 2) __builtin_amdgcn_s_setprio(1);
+        int g = 0;
+        R50_STAMP_DECL
+        // one chunk of group A: c = 2 c2 + PAR; `r` is the register set of its parity
+        auto chunk_a = [&](auto par_c, int c2, u32x4 (&r)[NR]) {
+            constexpr int PAR = decltype(par_c)::value;
+            const int c = 2 * c2 + PAR;
+            {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + B3_OFF + (c * 128 + 32 * w + 8 * fq) * 4);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + B3_OFF + (c * 128 + 32 * w + 8 * fq + 4) * 4);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) { accA[0][j] = lo; accA[1][j] = hi; }
+            }
+            using PA = std::integral_constant<int, T3P_PDA>;
+            using W4 = std::integral_constant<int, 4>;
+            using XP = std::integral_constant<bool, (T3P_XPRE & 1) != 0>;
+            w_step(PA{}, W4{}, NO{}, XP{}, g + 0, 0, wq[0], smem + T2 + 0 * SLOT, smem + T2 + 1 * SLOT, accA[0], accA[1], xq);
+            w_step(PA{}, W4{}, XP{}, XP{}, g + 1, 0, wq[1], smem + T2 + 1 * SLOT, smem + T2 + 2 * SLOT, accA[0], accA[1], xq);
+            w_step(PA{}, W4{}, XP{}, XP{}, g + 2, 0, wq[2], smem + T2 + 2 * SLOT, smem + T2 + 3 * SLOT, accA[0], accA[1], xq);
+            w_step(PA{}, W4{}, XP{}, NO{}, g + 3, 0, wq[3], smem + T2 + 3 * SLOT, smem + T2, accA[0], accA[1], xq);
+            g += 4;
+#if defined(R50_STAMP)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 0" ::"v"(accA[1][NR - 1]), "v"(accA[0][NR - 1]) : "memory");   // the stamp waits for the last MFMAs
+#endif
+            R50_MARK(0)                           // A: 4 weight steps
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- E: + identity, ReLU, 16 bit -> out_c[c & 1] and (T3P_COPY = 0) the block output; the identity of chunk c + 2 (of the next
+            // tile after chunks 6 and 7) is requested into the registers this chunk has just consumed
+            if (T3P_PRIO & 4) __builtin_amdgcn_s_setprio(2);
+            const bool nxt = (c2 == NCH / 2 - 1);
+            const int cofs_n = __builtin_amdgcn_readfirstlane(((c + 2) & (NCH - 1)) * 256);
+            const int cofs_c = __builtin_amdgcn_readfirstlane(c * 256);
+            char* ob = smem + OUTC + PAR * 2 * SLOT + c_frag;
+            u32x4 o[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                if (!(T3P_ABL & 8)) {
+                    f32x4 lo = accA[0][j], hi = accA[1][j];
+                    lo[0] += unpack_lo_e<ET>(r[j][0]); lo[1] += unpack_hi_e<ET>(r[j][0]);
+                    lo[2] += unpack_lo_e<ET>(r[j][1]); lo[3] += unpack_hi_e<ET>(r[j][1]);
+                    hi[0] += unpack_lo_e<ET>(r[j][2]); hi[1] += unpack_hi_e<ET>(r[j][2]);
+                    hi[2] += unpack_lo_e<ET>(r[j][3]); hi[3] += unpack_hi_e<ET>(r[j][3]);
+                    o[j] = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[j][e] = relu_bf16x2(o[j][e]);
+                    if (ROWS >= 16 * j + 16 || fr < ROWS - 16 * j) *reinterpret_cast<u32x4*>(ob + j * 2048) = o[j];
+                } else o[j] = r[j];
+                if (!(T3P_ABL & 1)) r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, nxt ? rvn[j] : rv[j], cofs_n, 0);
+            }
+            if (T3P_COPY == 0 && !(T3P_ABL & 2)) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) __builtin_amdgcn_raw_buffer_store_b128(o[j], rs_out, rv[j], cofs_c, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // out_c written before anybody reads it
+            if (T3P_PRIO & 4) __builtin_amdgcn_s_setprio((T3P_PRIO & 2) ? 1 : 0);
+            R50_MARK(1)                           // E
+            __builtin_amdgcn_s_barrier();
+            R50_MARK(2)                           // chunk barrier
+        };
+        for (int tile = first; tile < a.n_tiles; tile += grid) {
+            for (int c2 = 0; c2 < NCH / 2; ++c2) {
+                chunk_a(std::integral_constant<int, 0>{}, c2, r0);
+                chunk_a(std::integral_constant<int, 1>{}, c2, r1);
+            }
+            // ---- ninth interval: group B is on chunk 7; the T2 region is free -> the next tile's t2 rows
+            issue_t2(tile + grid);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) rv[j] = rvn[j];
+            tile_rows(tile + 2 * grid, rvn);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            R50_MARK(3)                           // t2 issue + landing
+            __builtin_amdgcn_s_barrier();
+            R50_MARK(4)                           // ninth barrier
+        }
+        R50_STAMP_FLUSH(8)
+    } else {
+        // =============================== group B: next conv1 + copy-out ==============================
+        const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.M * (C1N * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.M * (COUT * 2u), 0x00020000);
+        f32x4 accB[4][NR];
+        unsigned rvo[OC_PASSES];                   // block-output offsets of the lane's copy-out rows (row R = 32 i + srow of [2 slots][ROWS])
+        auto tile_rows = [&](int tile) {
+            const int p0 = tile * a.bp;
+            const int limit = (a.M - p0 < a.bp) ? a.M - p0 : a.bp;
+#pragma unroll
+            for (int i = 0; i < OC_PASSES; ++i) {
+                const int R = 32 * i + srow;
+                const int sl = R / ROWS, prow = R - ROWS * sl;
+                const int lchunk = (lt & 7) ^ (prow & 7);
+                rvo[i] = (sl < 2 && prow < limit) ? (unsigned)((p0 + prow) * COUT + sl * 64 + lchunk * 8) * 2u : kOobOffset;
+            }
+        };
+        auto y1n_store = [&](int tile) {
+            const int p0 = tile * a.bp;
+            const int limit = (a.M - p0 < a.bp) ? a.M - p0 : a.bp;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const f32x4 lo = accB[2 * t][j], hi = accB[2 * t + 1][j];
+                    u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                    const unsigned voff = (16 * j + fr < limit) ? (unsigned)((p0 + 16 * j + fr) * C1N + 128 * t + 32 * w + 8 * fq) * 2u : kOobOffset;
+                    if (!(T3P_ABL & 2) || o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, voff, 0, 0);
+                }
+        };
+        w_load_half(0, 4, wA, 0); w_load_half(0, 4, wA, 1);
+        w_load_half(1, 4, wB, 0); w_load_half(1, 4, wB, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // P
+        if (T3P_PRIO & 1) __builtin_amdgcn_s_setprio(1);
+        int g = 0;
+        int prev = -1;
+        R50_STAMP_DECL
+        for (int tile = first; tile < a.n_tiles; tile += grid) {
+            // ---- first interval (group A is on chunk 0): the previous tile's y1n leaves, the accumulators restart at b1
+            if (prev >= 0) y1n_store(prev);
+            prev = tile;
+            tile_rows(tile);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {         // accB[2t + e]: channels 128t + 32w + 8fq + 4e ..
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + B1_OFF + (128 * t + 32 * w + 8 * fq) * 4);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + B1_OFF + (128 * t + 32 * w + 8 * fq + 4) * 4);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) { accB[2 * t][j] = lo; accB[2 * t + 1][j] = hi; }
+            }
+            R50_MARK(0)                           // first interval: y1n of the previous tile, accumulator init
+            __builtin_amdgcn_s_barrier();
+            R50_MARK(1)                           // first barrier
+            for (int c = 0; c < NCH; ++c) {
+                const char* xb = smem + OUTC + (c & 1) * 2 * SLOT;
+                using PB = std::integral_constant<int, T3P_PDB>;
+                using W2 = std::integral_constant<int, 2>;
+                using XP = std::integral_constant<bool, (T3P_XPRE & 2) != 0>;
+                w_step(PB{}, W2{}, NO{}, XP{}, g + 0, 4, wA, xb, xb, accB[0], accB[1], xq);
+                w_step(PB{}, W2{}, XP{}, XP{}, g + 1, 4, wB, xb, xb + SLOT, accB[2], accB[3], xq);
+                w_step(PB{}, W2{}, XP{}, XP{}, g + 2, 4, wA, xb + SLOT, xb + SLOT, accB[0], accB[1], xq);
+                w_step(PB{}, W2{}, XP{}, NO{}, g + 3, 4, wB, xb + SLOT, xb, accB[2], accB[3], xq);
+                g += 4;
+#if defined(R50_STAMP)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 0" ::"v"(accB[3][NR - 1]), "v"(accB[2][NR - 1]), "v"(accB[1][NR - 1]), "v"(accB[0][NR - 1]) : "memory");
+#endif
+                R50_MARK(2)                       // B: 4 weight steps
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- (T3P_COPY = 1) copy-out of out_c[c & 1]: full 128-B row pieces, 16 B per lane
+                if (T3P_COPY) {
+                    const int cofs = __builtin_amdgcn_readfirstlane(c * 256);
+                    u32x4 v[OC_PASSES];
+#pragma unroll
+                    for (int i = 0; i < OC_PASSES; ++i) v[i] = *reinterpret_cast<const u32x4*>(xb + i * 4096 + lt * 16);
+#pragma unroll
+                    for (int i = 0; i < OC_PASSES; ++i)
+                        if (!(T3P_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, rvo[i], cofs, 0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of out_c[c & 1] are complete
+                R50_MARK(3)                       // copy-out
+                __builtin_amdgcn_s_barrier();
+                R50_MARK(4)                       // chunk barrier
+            }
+        }
+        if (prev >= 0) y1n_store(prev);
         R50_STAMP_FLUSH(8)
     }
 #else

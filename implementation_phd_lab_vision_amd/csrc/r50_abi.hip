@@ -782,8 +782,12 @@ hipError_t pack_tail3_weights(const void* w3, const void* w1, void* wp, hipStrea
     hipLaunchKernelGGL(tail3_pack_kernel, dim3(65536 / 256), dim3(256), 0, s, (const __bf16*)w3, (const __bf16*)w1, (__bf16*)wp);
     return hipGetLastError();
 }
+// variant: 0 = bneck_tail3_kernel (4 consumer + 4 helper waves), 1 = bneck_tail3p_kernel (two-group pipeline, 112 LDS rows per slot),
+// 2 = the same with 98 rows per slot.  Default for the network: g_tail3_variant (env R50_TAIL3_VAR, option "tail3_variant").
+int g_tail3_variant = [] { const char* v = std::getenv("R50_TAIL3_VAR"); return v ? std::atoi(v) : 0; }();
 hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const float* b3, const void* res, void* out,
-                              const float* b1, void* y1n, hipStream_t s, int et = 0, int bp_override = 0) {
+                              const float* b1, void* y1n, hipStream_t s, int et = 0, int bp_override = 0, int variant = -1) {
+    if (variant < 0) variant = g_tail3_variant;
     if (!y2 || !wp || !b3 || !res || !out || !b1 || !y1n || m <= 0 || m * 2048 >= (1ll << 31)) return hipErrorInvalidValue;
     if (g_num_cus == 0) {
         int dev = 0;
@@ -797,14 +801,25 @@ hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const
 #if defined(R50_STAMP)
     a.dbg = g_dbg;
 #endif
-    const long long rounds = ((m + 111) / 112 + g_num_cus - 1) / g_num_cus;
+    const int rows = variant == 2 ? 98 : 112;
+    const long long rounds = ((m + rows - 1) / rows + g_num_cus - 1) / g_num_cus;
     long long bp = (m + rounds * g_num_cus - 1) / (rounds * g_num_cus);
     if (bp < 49) bp = 49;
-    if (bp > 112) bp = 112;
-    if (bp_override >= 1 && bp_override <= 112) bp = bp_override;
+    if (bp > rows) bp = rows;
+    if (bp_override >= 1 && bp_override <= rows) bp = bp_override;
     a.bp = (int)bp;
     a.n_tiles = (int)((m + bp - 1) / bp);
     const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
+    if (variant == 1 || variant == 2) {
+        const size_t ldsp = 8 * (size_t)rows * 128 + 256 * 4 + 1024 * 4;      // t2 (4 slots) + out_c (2 x 2) + b1 + b3
+        void (*kp)(const Tail3Args);
+        if (variant == 1) kp = et == 1 ? bneck_tail3p_kernel<1, 112> : bneck_tail3p_kernel<0, 112>;
+        else kp = et == 1 ? bneck_tail3p_kernel<1, 98> : bneck_tail3p_kernel<0, 98>;
+        hipError_t ep = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+        if (ep != hipSuccess) return ep;
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(512), ldsp, s, a);
+        return hipGetLastError();
+    }
     const size_t lds = 10 * 112 * 128 + 256 * 4 + 1024 * 4;      // t2 (4 slots) + residual (2 x 2) + out_c (2) + b1 + b3
     auto kern = et == 1 ? bneck_tail3_kernel<1> : bneck_tail3_kernel<0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1724,6 +1739,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "fused_stem") h->fused_stem = value ? 1 : 0;
     else if (k == "fuse_tail") h->fuse_tail = value ? 1 : 0;
     else if (k == "fuse_tail3") h->fuse_tail3 = value ? 1 : 0;
+    else if (k == "tail3_variant") { if (value < 0 || value > 2) return fail(h, R50_ERR_INVALID, "tail3_variant must be 0, 1 or 2"); g_tail3_variant = (int)value; }
     else if (k == "fuse_fp8_handover") h->fuse_fp8_handover = value ? 1 : 0;
     else if (k == "fuse_stem_c1") h->fuse_stem_c1 = value ? 1 : 0;
     else if (k == "fuse_ds_cat") h->fuse_ds_cat = value ? 1 : 0;
@@ -1757,6 +1773,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "fused_stem") *value = h->fused_stem;
     else if (k == "fuse_tail") *value = h->fuse_tail;
     else if (k == "fuse_tail3") *value = h->fuse_tail3;
+    else if (k == "tail3_variant") *value = g_tail3_variant;
     else if (k == "fuse_fp8_handover") *value = h->fuse_fp8_handover;
     else if (k == "fuse_stem_c1") *value = h->fuse_stem_c1;
     else if (k == "fuse_ds_cat") *value = h->fuse_ds_cat;
@@ -1897,13 +1914,14 @@ int r50_op_bneck_tail(const void* y2, int64_t m, int cmid, const void* w3, const
     else if (cmid == 128 && c1 == 128 && !wd && !bd) e = launch_bneck_tail2(y2, m, w3, b3, res, out, w1, b1, y1n, (hipStream_t)stream);
     else if (cmid == 256 && c1 == 256 && !wd && !bd) {
         const char* v = std::getenv("R50_TAIL3_BP");          // test / A-B knob of this debug hook: real pixels per tile (1..112); unset = automatic
+        const char* vv = std::getenv("R50_TAIL3_VAR");        // kernel variant (launch_bneck_tail3), read per call so that one process can A/B
         // the hook takes plain weight matrices: packed here, per call, into a buffer allocated AND freed in the caller's stream order on the
         // caller's current device (a process-wide scratch buffer would be shared by callers on other streams / devices: round-2 ADVICE)
         void* wp_scratch = nullptr;
         if (hipMallocAsync(&wp_scratch, kTail3PackedBytes, (hipStream_t)stream) != hipSuccess || !wp_scratch)
             return fail(nullptr, R50_ERR_HIP, "r50_op_bneck_tail: hipMallocAsync");
         e = pack_tail3_weights(w3, w1, wp_scratch, (hipStream_t)stream);
-        if (e == hipSuccess) e = launch_bneck_tail3(y2, m, wp_scratch, b3, res, out, b1, y1n, (hipStream_t)stream, 0, v ? std::atoi(v) : 0);
+        if (e == hipSuccess) e = launch_bneck_tail3(y2, m, wp_scratch, b3, res, out, b1, y1n, (hipStream_t)stream, 0, v ? std::atoi(v) : 0, vv ? std::atoi(vv) : -1);
         const hipError_t ef = hipFreeAsync(wp_scratch, (hipStream_t)stream);
         if (e == hipSuccess) e = ef;
     }
