@@ -186,6 +186,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="frames per GPU per step (headline config: 256)")
     ap.add_argument("--micro-batch", type=int, default=0)
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="independent batches in flight (backbone.BackboneLanes: one backbone copy + HIP stream per lane, steps dealt round "
+                         "robin): the next step's launches fill the CUs that the previous step's launch tails leave idle.  1 = the steps run "
+                         "strictly one after the other on one stream (also reported in the line as `single_lane`)")
     ap.add_argument("--streams", type=int, default=0, help="internal streams the batch is split over (0 = library default)")
     ap.add_argument("--precision", choices=["bf16", "fp16", "bf16w2", "fp32x", "fp8"], default="bf16",
                     help="bf16 = headline path; fp32x = fp32-class accuracy mode (bf16 head/tail pairs, 3 products per conv); "
@@ -255,25 +259,40 @@ def main() -> None:
         dist.barrier()
 
     sd = synthetic_state_dict(0)
-    bb = ResNet50Backbone(state_dict=sd, max_batch=args.batch, micro_batch=args.micro_batch, precision=args.precision).to(dev).eval()
+    if args.from_host or args.input != "f32":
+        args.lanes = 1                     # the PCIe-inclusive and the uint8 / video variants are single-lane measurements
+    n_lanes = max(1, args.lanes)
+    lanes = None
+    if n_lanes > 1:
+        from implementation_phd_lab_vision_amd.backbone import BackboneLanes
+        lanes = BackboneLanes(lanes=n_lanes, state_dict=sd, max_batch=args.batch, micro_batch=args.micro_batch, precision=args.precision).to(dev).eval()
+        bb = lanes.lane0                   # lane 0 alone: the output check, the per-class event profile, the single-lane figure
+    else:
+        bb = ResNet50Backbone(state_dict=sd, max_batch=args.batch, micro_batch=args.micro_batch, precision=args.precision).to(dev).eval()
+    _lane0 = bb
+
+    class _AllLanes:                       # options go to every lane
+        def set_option(self, k, v):
+            (lanes or _lane0).set_option(k, v)
+    bb_opts = _AllLanes()
     if args.streams:
-        bb.set_option("streams", args.streams)
+        bb_opts.set_option("streams", args.streams)
     if args.no_fused_stem:
-        bb.set_option("fused_stem", 0)
+        bb_opts.set_option("fused_stem", 0)
     if args.no_stem_c1:
-        bb.set_option("fuse_stem_c1", 0)
+        bb_opts.set_option("fuse_stem_c1", 0)
     if args.no_ds_cat:
-        bb.set_option("fuse_ds_cat", 0)
+        bb_opts.set_option("fuse_ds_cat", 0)
     if args.no_fuse_tail:
-        bb.set_option("fuse_tail", 0)
+        bb_opts.set_option("fuse_tail", 0)
     if args.no_overlap_ds:
-        bb.set_option("overlap_ds", 0)
+        bb_opts.set_option("overlap_ds", 0)
     if args.inplace:
-        bb.set_option("inplace_out", 1)
+        bb_opts.set_option("inplace_out", 1)
     if args.no_block2:
-        bb.set_option("fuse_block2", 0)
+        bb_opts.set_option("fuse_block2", 0)
     if args.block1 >= 0:
-        bb.set_option("fuse_block1", args.block1)
+        bb_opts.set_option("fuse_block1", args.block1)
     x = synthetic_frames(args.batch, seed=1234 + rank).to(dev)          # random data, resident in HBM
     run = bb.features
     if args.input == "u8":
@@ -288,14 +307,16 @@ def main() -> None:
 
         def run(frames, out=None):
             return bb.features_u8(crop_and_resize_video_uint8(frames, box), out=out)
-    feats = torch.empty((args.batch, 2048), dtype=torch.float32, device=dev)
+    feats_l = [torch.empty((args.batch, 2048), dtype=torch.float32, device=dev) for _ in range(n_lanes)]      # one output buffer per lane
+    feats = feats_l[0]
     gathered = [torch.empty_like(feats) for _ in range(world)] if (dist is not None and rank == 0) else None
 
-    def gather_feats():
+    def gather_feats(f=None):
+        f = feats if f is None else f
         if rehearsal:                    # gloo has no device-tensor gather: through host copies (control flow only)
-            dist.gather(feats.cpu(), [g.cpu() for g in gathered] if rank == 0 else None, dst=0)
+            dist.gather(f.cpu(), [g.cpu() for g in gathered] if rank == 0 else None, dst=0)
         else:
-            dist.gather(feats, gathered, dst=0)
+            dist.gather(f, gathered, dst=0)
 
     if args.from_host:
         x_host = x.cpu().pin_memory()
@@ -320,6 +341,23 @@ def main() -> None:
             state["k"] = k + 1
             if dist is not None:
                 gather_feats()
+    elif lanes is not None:
+        lane_state = {"k": 0, "free": [None] * n_lanes}
+
+        def step():
+            # step k on lane k % L: its launches are queued behind the lane's previous step only; x is static and feats_l[lane] is free
+            # once the gather that read it (multi-rank runs) has run -- `free[lane]`, recorded on the main stream behind that gather
+            k = lane_state["k"]
+            lane = k % n_lanes
+            t = lanes.submit(x, out=feats_l[lane], after=lane_state["free"][lane])
+            if dist is not None:
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_event(t.event)
+                gather_feats(feats_l[lane])
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                lane_state["free"][lane] = ev
+            lane_state["k"] = k + 1
     else:
         def step():
             run(x, out=feats)
@@ -348,6 +386,19 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    single_lane = None
+    if lanes is not None:
+        torch.cuda.synchronize(dev)
+        lanes_agree = all(bool(torch.equal(feats_l[0], f)) for f in feats_l[1:])
+        if dist is None:                   # the same K steps strictly one after the other on lane 0 (no second batch in flight)
+            def step1():
+                run(x, out=feats)
+            el1, _ = timed_steps(step1, fence, args.steps, 1, min(args.preheat, 0.3), args.batch, None)
+            single_lane = {"value": args.batch * args.steps / el1, "unit": "frames/s", "ms_per_step": 1e3 * el1 / args.steps,
+                           "note": "lanes = 1: every step waits for the previous one's last launch (the measurement of rounds 1-2)"}
+    else:
+        lanes_agree = None
+
     # ---- the timed output is checked (outside the timed region): finite, and frames 0 / last equal to the same two frames run
     #      alone as a batch of 2 (the kernels' tile choice, persistent tile streams and ragged last tiles differ between the two runs;
     #      the arithmetic per frame must not)
@@ -359,6 +410,10 @@ def main() -> None:
         if not finite:
             failure = "non-finite features in the timed output"
         checked = {"finite": finite}
+        if lanes_agree is not None:
+            checked["lanes_equal"] = lanes_agree
+            if not lanes_agree:
+                failure = "the lanes' outputs for the same batch differ"
         if finite and not args.no_check:
             pick = [0, args.batch - 1] if args.batch > 1 else [0]
             small = bb.features(x[pick].contiguous())
@@ -464,7 +519,7 @@ def main() -> None:
     secondary = {}
     acc_in = {}
     if rank == 0 and world == 1 and not args.no_secondary and args.precision == "bf16" and args.input == "f32" and not args.from_host:
-        bb.close()                    # frees the headline handle's workspace before the secondary ones are created
+        (lanes or bb).close()         # frees the headline handles' workspaces before the secondary ones are created
         torch.cuda.empty_cache()
         for prec, b in (("fp16", 256), ("fp8", 512)):
             secondary[f"{prec}_b{b}"], acc_in[prec] = secondary_mode(prec, b, args.steps, args.warmup, min(args.preheat, 0.5), dev, sd)
@@ -501,12 +556,14 @@ def main() -> None:
                                    f"(BASELINE configs[{4 if args.precision == 'fp8' else 1}]), seeded synthetic weights, (N,2048) fp32 features"
                                    + (", RCCL gather to rank 0" if dist_used else ""),
                        "batch_per_gpu": args.batch, "micro_batch": args.micro_batch,
+                       "lanes": n_lanes, "lanes_note": (f"{n_lanes} independent batches in flight, each on its own backbone copy + HIP stream (steps dealt round robin; "
+                                                        "every step is a whole batch-%d forward; nothing is shared or skipped)" % args.batch) if n_lanes > 1 else "one batch at a time",
                        "input": args.input + (" from pinned host memory every step (PCIe-inclusive, H2D overlapped)" if args.from_host else ""),
                        "parallelism": f"frames sharded over {world} rank(s)"},
             "tflops": value * GFLOP_PER_FRAME / 1e3,
             "frac_of_mfma_peak_whole_step": value * GFLOP_PER_FRAME / 1e3 / MFMA_BF16_PEAK_TFLOPS / world,
             "preheat": {"seconds": args.preheat, "frames_per_s": preheat_rate},
-            "checked": checked,
+            "checked": checked, "single_lane": single_lane,
             # the tolerance statement of the HEADLINE mode: bf16 is the reference's own GPU dtype (torch.autocast(bfloat16),
             # src/preprocess_resnet_features.py:290-294) and lands 2.5e-3 from the fp32/fp64 view of the network (weight rounding);
             # north_star's 1e-3 is met by the fp16 mode (secondary `fp16_b256`, same kernels with IEEE half operands)

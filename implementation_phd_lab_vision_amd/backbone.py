@@ -273,3 +273,154 @@ class ResNet50Backbone:
             self._release()
         except Exception:
             pass
+
+
+class LaneTicket:
+    """One batch in flight on a lane: ``out`` is complete once ``event`` has fired (``wait()`` orders the current stream behind it)."""
+    __slots__ = ("out", "event", "lane")
+
+    def __init__(self, out: torch.Tensor, event: "torch.cuda.Event", lane: int):
+        self.out, self.event, self.lane = out, event, lane
+
+    def wait(self, stream: Optional["torch.cuda.Stream"] = None) -> torch.Tensor:
+        (stream or torch.cuda.current_stream(self.out.device)).wait_event(self.event)
+        return self.out
+
+
+class BackboneLanes:
+    """Several independent batches in flight on one MI355X: ``lanes`` copies of the backbone, each on its own HIP stream.
+
+    Why: a forward pass is 35 launches of persistent kernels, one workgroup per CU; every launch has a head (cold LDS, the
+    first tiles' operands) and a tail (the last workgroups finishing alone), and the next launch of the SAME batch cannot start
+    before the tail has drained.  Batches are independent (the reference's call site runs them one after the other,
+    src/preprocess_resnet_features.py:287-297), so with two batches in flight the workgroups of one batch's next launch fill the
+    CUs the other batch's tail leaves idle: +5 % frames/s at batch 256 with the same bits (scripts/dual_stream_probe.py).
+    Each lane owns its activation buffers (and, today, its own copy of the 47 MB of weights).
+
+    ``submit`` enqueues a batch on the next lane and returns at once; the caller orders later work behind ``ticket.event``.
+    ``features`` / ``__call__`` keep the one-batch surface of ``ResNet50Backbone`` (current stream waits for the result)."""
+
+    def __init__(self, lanes: int = 2, **backbone_kwargs):
+        if lanes < 1:
+            raise ValueError("lanes must be >= 1")
+        sd = backbone_kwargs.pop("state_dict", None)
+        if sd is None:
+            wp = backbone_kwargs.pop("weights_path", None)
+            sd = load_state_dict_from_path(wp) if wp else synthetic_state_dict(backbone_kwargs.pop("seed", 0))
+        self._bbs = [ResNet50Backbone(state_dict=sd, **backbone_kwargs) for _ in range(lanes)]
+        self._streams = []
+        self._next = 0
+        self._device: Optional[torch.device] = None
+        self.training = False
+
+    # ---- nn.Module-like surface -------------------------------------------------------------
+    def to(self, device) -> "BackboneLanes":
+        for bb in self._bbs:
+            bb.to(device)
+        self._device = self._bbs[0]._device
+        if len(self._streams) != len(self._bbs):
+            self._streams = [torch.cuda.Stream(self._device) for _ in self._bbs]
+        if self._bbs[0]._precision == PREC_FP8:      # one calibration for all lanes: the features must not depend on the lane
+            for bb in self._bbs[1:]:
+                bb.set_fp8_scales(self._bbs[0].fp8_scales)
+        return self
+
+    def cuda(self, device=None) -> "BackboneLanes":
+        return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
+
+    def eval(self) -> "BackboneLanes":
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise _lib.R50Error("the backbone is inference-only (the reference calls .eval(), :209)")
+        return self
+
+    @property
+    def lanes(self) -> int:
+        return len(self._bbs)
+
+    @property
+    def lane0(self) -> ResNet50Backbone:
+        return self._bbs[0]
+
+    @property
+    def fp8_scales(self):
+        return self._bbs[0].fp8_scales
+
+    def set_option(self, key: str, value: int) -> None:
+        for bb in self._bbs:
+            bb.set_option(key, value)
+
+    def get_option(self, key: str) -> int:
+        return self._bbs[0].get_option(key)
+
+    def set_fp8_scales(self, scales) -> None:
+        for bb in self._bbs:
+            bb.set_fp8_scales(scales)
+
+    def calibrate_fp8(self, frames: Optional[torch.Tensor] = None, margin: float = FP8_MARGIN):
+        scales = self._bbs[0].calibrate_fp8(frames=frames, margin=margin)
+        for bb in self._bbs[1:]:
+            bb.set_fp8_scales(scales)
+        return scales
+
+    # ---- batches in flight ------------------------------------------------------------------
+    def submit(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, after: Optional["torch.cuda.Event"] = None,
+               u8: bool = False) -> LaneTicket:
+        """Enqueue one batch on the next lane (round robin) and return without waiting.
+
+        ``after``: event the lane waits for before it touches ``x`` / ``out`` (their producer / previous consumer); None = the
+        caller guarantees both are ready (static inputs).  The lane's previous batch is ordered before this one by its stream.
+        The caller keeps ``x`` and ``out`` alive until ``ticket.event`` has fired (``ticket.wait()``), and allocates ``out`` itself
+        when it is given: a tensor made here is allocated on the CURRENT stream and first written on the lane's, so when ``out`` is
+        None an ``after`` event is recorded on the current stream if none was passed."""
+        if self._device is None:
+            raise _lib.R50Error("call .to('cuda:N') before running the backbone")
+        lane = self._next
+        self._next = (lane + 1) % len(self._bbs)
+        bb, st = self._bbs[lane], self._streams[lane]
+        if out is None:
+            out = torch.empty((x.shape[0], FEATURE_DIM), dtype=torch.float32, device=self._device)
+            if after is None:
+                after = torch.cuda.Event()
+                after.record(torch.cuda.current_stream(self._device))
+        if after is not None:
+            st.wait_event(after)
+        with torch.cuda.stream(st):
+            (bb.features_u8 if u8 else bb.features)(x, out)
+            done = torch.cuda.Event()
+            done.record(st)
+        return LaneTicket(out, done, lane)
+
+    def features(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One batch, ordered like ``ResNet50Backbone.features``: runs behind everything queued on the current stream, and the
+        current stream waits for the result."""
+        cur = torch.cuda.current_stream(self._device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        return self.submit(x, out, after=ready).wait(cur)
+
+    def features_u8(self, x_u8: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        cur = torch.cuda.current_stream(self._device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        return self.submit(x_u8, out, after=ready, u8=True).wait(cur)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        return self.features(x).view(x.shape[0], FEATURE_DIM, 1, 1)
+
+    forward = __call__
+
+    def layer(self, x: torch.Tensor, name: str) -> torch.Tensor:
+        return self._bbs[0].layer(x, name)
+
+    def drain(self) -> None:
+        """The current stream waits for everything submitted so far."""
+        cur = torch.cuda.current_stream(self._device)
+        for st in self._streams:
+            cur.wait_stream(st)
+
+    def close(self) -> None:
+        for bb in self._bbs:
+            bb.close()

@@ -169,9 +169,10 @@ struct ConvArgs {
 
 // In-kernel cycle stamps of the role-specialised kernel (diagnostic build -DR50_STAMP=1 only).
 #if defined(R50_STAMP)
-#define R50_STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define R50_STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();
 #define R50_MARK(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long st_now = __builtin_readcyclecounter(); st_sum[i] += st_now - st_prev; st_prev = st_now; __builtin_amdgcn_sched_barrier(0); }
-#define R50_STAMP_FLUSH(nw) if (a.dbg && (threadIdx.x & 63) == 0) { _Pragma("unroll") for (int q = 0; q < 8; ++q) \
+#define R50_STAMP_FLUSH(nw) st_sum[7] = __builtin_amdgcn_s_memrealtime() - st_rt0;   /* slot 7: 100-MHz ticks over the stamped region (held clock = cycles / ticks x 100 MHz) */ \
+    if (a.dbg && (threadIdx.x & 63) == 0) { _Pragma("unroll") for (int q = 0; q < 8; ++q) \
         a.dbg[((size_t)blockIdx.x * (nw) + (threadIdx.x >> 6)) * 8 + q] = st_sum[q]; }
 #else
 #define R50_STAMP_DECL
@@ -2915,7 +2916,7 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
 #define T3P_XPRE 0
 #endif
 #ifndef T3P_COPY          // who writes the block output: 0 = group A straight from its E-phase registers (64-B pieces), 1 = group B copies out_c out of LDS (full rows)
-#define T3P_COPY 0
+#define T3P_COPY 1        // stamps: 102 k cycles per wave and launch with the copy-out against 128 k with 64-B pieces from group A's registers
 #endif
 #ifndef T3P_PRIO          // wave priority: 1 = group B at s_setprio 1, 2 = group A at s_setprio 1, 4 = group A at s_setprio 2 during its E phase
 #define T3P_PRIO 0

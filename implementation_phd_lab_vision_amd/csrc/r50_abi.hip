@@ -784,7 +784,7 @@ hipError_t pack_tail3_weights(const void* w3, const void* w1, void* wp, hipStrea
 }
 // variant: 0 = bneck_tail3_kernel (4 consumer + 4 helper waves), 1 = bneck_tail3p_kernel (two-group pipeline, 112 LDS rows per slot),
 // 2 = the same with 98 rows per slot.  Default for the network: g_tail3_variant (env R50_TAIL3_VAR, option "tail3_variant").
-int g_tail3_variant = [] { const char* v = std::getenv("R50_TAIL3_VAR"); return v ? std::atoi(v) : 0; }();
+int g_tail3_variant = [] { const char* v = std::getenv("R50_TAIL3_VAR"); return v ? std::atoi(v) : 1; }();
 hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const float* b3, const void* res, void* out,
                               const float* b1, void* y1n, hipStream_t s, int et = 0, int bp_override = 0, int variant = -1) {
     if (variant < 0) variant = g_tail3_variant;

@@ -75,6 +75,9 @@ def build_parser() -> argparse.ArgumentParser:
                    help="--precision fp8: where the 43 activation scales come from.  first-batch = the first batch of REAL clips (decoded "
                         "once more, like the reference's warm-up batch, :235-245); noise = 8 synthetic uniform-noise frames (scales that fit "
                         "noise, not H36M crops: anything above 448 x scale clips silently)")
+    p.add_argument("--lanes", type=int, default=2,
+                   help="Backbone copies on their own HIP streams (backbone.BackboneLanes): under --augment the variants of a batch are "
+                        "independent forward passes and two are kept in flight (same bits, +5 %% frames/s); 1 = one stream")
     p.add_argument("--micro-batch", type=int, default=0, help="Frames per pass through the layer stack (0 = auto)")
     p.add_argument("--max-batch", type=int, default=256, help="Frames per backbone call chunk (workspace size)")
     p.add_argument("--no-trev-reuse", action="store_true",
@@ -202,20 +205,37 @@ def extract_features(backbone: Callable[[torch.Tensor], torch.Tensor], variants_
     by ``_aug_temporal_reverse`` from the same clip as variant 0: src/dataset.py:199-207,424-426) are the
     features of variant 0 in reverse frame order, bit for bit: under ``--augment`` that forward pass (a quarter of
     the work) is replaced by a flip.  Only when the frames really are the reverse (``prefetch.is_time_reverse_of``: every frame
-    takes part in the check, per batch)."""
+    takes part in the check, per batch).
+
+    The variants are independent forward passes: a backbone with lanes (``backbone.BackboneLanes``: has ``submit``) gets all of
+    them submitted before the first result is waited for, so two are in flight at a time (same bits, +5 % frames/s)."""
     per_variant = []
+    lanes = hasattr(backbone, "submit") and device.type == "cuda"
+    pending = []                                       # (slot in per_variant, ticket, input kept alive, (b, t))
+    ready = None
     for vi, (v_video, *_rest) in enumerate(variants_batch):
         if v_video is None:                            # the prefetcher found it to be the time reverse and did not upload it
-            per_variant.append(per_variant[0].flip(1))
+            per_variant.append("flip0")
             continue
         if (reuse_trev and len(variants_batch) == len(AUG_NAMES) and vi == AUG_NAMES.index("trev")
                 and v_video.device == variants_batch[0][0].device and is_time_reverse_of(v_video, variants_batch[0][0])):
-            per_variant.append(per_variant[0].flip(1))
+            per_variant.append("flip0")
             continue
         v_video = v_video.to(device, non_blocking=True)
         b, t, c, h, w = v_video.shape
         x = v_video.view(b * t, c, h, w).contiguous()
-        per_variant.append(backbone(x).flatten(1).view(b, t, -1).to(torch.float32))
+        if lanes:
+            if x.dtype != torch.float32:
+                x = x.to(torch.float32)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(device))       # x (and everything before it) is complete before the lane reads it
+            pending.append((len(per_variant), backbone.submit(x, after=ready), x, (b, t)))
+            per_variant.append(None)
+        else:
+            per_variant.append(backbone(x).flatten(1).view(b, t, -1).to(torch.float32))
+    for slot, ticket, _x, (b, t) in pending:
+        per_variant[slot] = ticket.wait().view(b, t, -1)
+    per_variant = [per_variant[0].flip(1) if isinstance(v, str) else v for v in per_variant]
     return torch.stack(per_variant, dim=1)
 
 
@@ -377,8 +397,16 @@ def main(argv: Optional[List[str]] = None) -> None:
     log(f"Weights    : {source}  (sha256 {digest[:16]}…)")
     if args.synthetic_weights:
         log("WARNING    : --synthetic-weights: the backbone is a RANDOM-initialised ResNet-50; the shards will NOT hold ImageNet features")
-    backbone = ResNet50Backbone(state_dict=state_dict, max_batch=args.max_batch, micro_batch=args.micro_batch,
-                                precision=args.precision).to(device).eval()
+    n_lanes = max(1, int(getattr(args, "lanes", 1)))
+    if n_lanes > 1 and args.augment and not args.device_producer:
+        from .backbone import BackboneLanes
+        backbone = BackboneLanes(lanes=n_lanes, state_dict=state_dict, max_batch=args.max_batch, micro_batch=args.micro_batch,
+                                 precision=args.precision).to(device).eval()
+        log(f"Lanes      : {n_lanes} backbone copies on their own streams (the variants of a batch run {n_lanes} at a time)")
+    else:
+        n_lanes = 1
+        backbone = ResNet50Backbone(state_dict=state_dict, max_batch=args.max_batch, micro_batch=args.micro_batch,
+                                    precision=args.precision).to(device).eval()
     if ctx.is_root:       # provenance beside the shards (index.pt keeps the reference's exact key set)
         import json
         Path(args.out).mkdir(parents=True, exist_ok=True)
@@ -390,7 +418,8 @@ def main(argv: Optional[List[str]] = None) -> None:
 
     log("Warming up the HIP kernels...")                               # reference warm-up: :235-245
     warm = torch.zeros((min(args.max_batch, args.batch_size * args.seq_len), 3, 224, 224), device=device)
-    backbone(warm)
+    for _ in range(n_lanes):
+        backbone(warm)
     torch.cuda.synchronize(device)
     del warm
     log("✓ Warmup complete\n")

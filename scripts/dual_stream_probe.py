@@ -35,13 +35,14 @@ def single(steps):
     return 256 * steps / dt, ref
 
 
-def dual(steps, cap, off_frac, n_pipes=2):
-    per = 256 // n_pipes
+def dual(steps, cap, off_frac, n_pipes=2, per=None):
+    full = per is not None                    # full = every pipe runs whole 256-frame batches (two batches in flight)
+    per = per or 256 // n_pipes
     bbs = [ResNet50Backbone(state_dict=sd, max_batch=per).to(dev).eval() for _ in range(n_pipes)]
     bbs[0].set_option('cu_cap', cap)          # process-wide
     streams = [torch.cuda.Stream(dev) for _ in range(n_pipes)]
     outs = [torch.empty(per, 2048, device=dev) for _ in range(n_pipes)]
-    xs = [x[i * per:(i + 1) * per].contiguous() for i in range(n_pipes)]
+    xs = [x if full else x[i * per:(i + 1) * per].contiguous() for i in range(n_pipes)]
     for i in range(n_pipes):
         with torch.cuda.stream(streams[i]):
             for _ in range(3): bbs[i].features(xs[i], outs[i])
@@ -58,9 +59,9 @@ def dual(steps, cap, off_frac, n_pipes=2):
                 bbs[i].features(xs[i], outs[i])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    res = torch.cat(outs)
+    res = outs[0] if full else torch.cat(outs)
     for b in bbs: b.close()
-    return 256 * steps / dt, res
+    return per * n_pipes * steps / dt, res
 
 
 base, ref = single(STEPS)
@@ -69,7 +70,13 @@ for cap in CAPS:
     for off in OFFS:
         v, res = dual(STEPS, cap, off)
         print(f"2 pipes x 128 frames, cu_cap {cap:3d}, offset {off:.2f}: {v:9.0f} frames/s  ({v / base - 1:+.1%})  equal={torch.equal(res, ref)}")
-for cap in (64, 86):
+if len(sys.argv) > 4:                         # whole batches on two streams, every grid uncapped: launch tails of one fill with the other's heads
+    for cap in CAPS:
+        v, res = dual(STEPS, cap, 0.0, n_pipes=2, per=256)
+        print(f"2 pipes x 256 frames, cu_cap {cap:3d}: {v:9.0f} frames/s  ({v / base - 1:+.1%})  equal={torch.equal(res, ref)}")
+        v, res = dual(STEPS, cap, 0.5, n_pipes=2, per=256)
+        print(f"2 pipes x 256 frames, cu_cap {cap:3d}, offset 0.5: {v:9.0f} frames/s  ({v / base - 1:+.1%})  equal={torch.equal(res, ref)}")
+for cap in (() if len(sys.argv) > 4 else (64, 86)):
     v, res = dual(STEPS, cap, 0.5, n_pipes=4)
     print(f"4 pipes x  64 frames, cu_cap {cap:3d}, offset 0.50: {v:9.0f} frames/s  ({v / base - 1:+.1%})  equal={torch.equal(res, ref)}")
 base2, _ = single(STEPS)

@@ -27,5 +27,6 @@ for name, arr, labels in (("group A", t[:, :4, :], ["A (4 steps)", "E", "chunk b
     m = arr.mean(dim=(0, 1))
     tot = m[:len(labels)].sum()
     print(f"{name}: total {tot:.0f} cycles per wave (whole launch, 2 tiles = 16 chunks)")
+    print(f"   held clock: {100.0 * tot / m[7]:.0f} MHz ({m[7] / 100:.1f} us stamped)")
     for i, l in enumerate(labels):
         print(f"   {l:20s} {m[i]:9.0f}  {100 * m[i] / tot:5.1f}%   per chunk {m[i] / 16:7.0f}")

@@ -53,6 +53,25 @@ def test_cli_augment_trev_reuse_gives_identical_files(tmp_path, lib_built):
         assert [m["aug"] for m in sa["meta"]] == [m["aug"] for m in sb["meta"]]
 
 
+def test_cli_augment_lanes_give_identical_files(tmp_path, lib_built):
+    """--augment with two backbone lanes (the default: the variants of a batch run two at a time on their own streams) writes, tensor
+    for tensor, the shards of the single-stream run."""
+    from implementation_phd_lab_vision_amd.preprocess_resnet_features import main
+    common = ["--root", "unused", "--synthetic-clips", "5", "--seq-len", "3", "--batch-size", "2", "--num-workers", "0",
+              "--shard-size", "3", "--shuffle-pool", "4", "--shuffle-seed", "3", "--device", "cuda", "--max-batch", "16", "--augment", "--synthetic-weights",
+              "--no-trev-reuse"]
+    a, b = tmp_path / "lanes2", tmp_path / "lanes1"
+    main(common + ["--out", str(a)])
+    main(common + ["--out", str(b), "--lanes", "1"])
+    ia, ib = torch.load(a / "index.pt", weights_only=True), torch.load(b / "index.pt", weights_only=True)
+    assert ia["n_variants"] == 4 and ia["clips"] == ib["clips"] and ia["n_shards"] == ib["n_shards"]
+    for sid in range(ia["n_shards"]):
+        sa = torch.load(a / f"shard_{sid:05d}.pt", weights_only=True)
+        sb = torch.load(b / f"shard_{sid:05d}.pt", weights_only=True)
+        for key in ("feats", "joints3d", "joints2d", "K"):
+            assert torch.equal(sa[key], sb[key]), (sid, key)
+
+
 def test_cli_with_a_checkpoint_file(tmp_path, lib_built):
     """--weights PATH: a torchvision-layout checkpoint (with fc.*, num_batches_tracked, a `module.` prefix) written to disk
     gives the same shards as the same weights handed over in memory, and its provenance is recorded beside the shards."""

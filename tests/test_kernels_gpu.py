@@ -320,15 +320,18 @@ def _tail3_inputs(n, h, w, seed):
     return y2, w3, b3, idn, w1, b1
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=lambda v: "var%d" % v)
 @pytest.mark.parametrize("shape,bp", [((2, 7, 9), 0), ((1, 14, 14), 0), ((3, 14, 14), 112), ((3, 14, 14), 98), ((20, 14, 14), 7), ((5, 14, 14), 33)],
                          ids=lambda v: str(v).replace(" ", ""))
-def test_bneck_tail_layer3_shapes(lib_built, shape, bp, monkeypatch):
+def test_bneck_tail_layer3_shapes(lib_built, shape, bp, variant, monkeypatch):
     """Chained layer3 tail (conv3 256->1024 + identity + ReLU, next conv1 1024->256 + ReLU; weights streamed through the LDS ring,
     the residual as one more K-step against an identity operand, the block output handed to the second GEMM through LDS).
     Against the oracle's two fused-op emulations, and BIT FOR BIT against the two igemm launches it replaces (same summation
-    orders).  bp = real pixels per tile: ragged tiles, several tiles per workgroup (bp 7: 560 tiles) and the batch-256 value (98)."""
+    orders).  bp = real pixels per tile: ragged tiles, several tiles per workgroup (bp 7: 560 tiles) and the batch-256 value (98).
+    variant: 0 = bneck_tail3_kernel, 1 / 2 = bneck_tail3p_kernel (two-group pipeline; 112 / 98 LDS rows per slot: bp 112 is capped at 98 there)."""
     from implementation_phd_lab_vision_amd import ops
     from oracle.resnet50_oracle import conv_bias_act_emulated
+    monkeypatch.setenv("R50_TAIL3_VAR", str(variant))
     n, h, w = shape
     y2, w3, b3, idn, w1, b1 = _tail3_inputs(n, h, w, 3000 + n * h * w + bp)
     d = _dev()
@@ -358,10 +361,12 @@ def test_bneck_tail_layer3_shapes(lib_built, shape, bp, monkeypatch):
         _check_bf16(y1n, y1_ref, "bneck_tail3 y1n")
 
 
-def test_bneck_tail_layer3_batch256_equals_unfused(lib_built, monkeypatch):
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=lambda v: "var%d" % v)
+def test_bneck_tail_layer3_batch256_equals_unfused(lib_built, variant, monkeypatch):
     """The benchmarked size (256 x 14 x 14 = 50,176 pixels -> 512 tiles of 98, two per workgroup): bit-identical to the launches it replaces."""
     from implementation_phd_lab_vision_amd import ops
     monkeypatch.delenv("R50_TAIL3_BP", raising=False)
+    monkeypatch.setenv("R50_TAIL3_VAR", str(variant))
     y2, w3, b3, idn, w1, b1 = _tail3_inputs(256, 14, 14, 3999)
     d = _dev()
     y2d = y2.permute(0, 2, 3, 1).contiguous().to(d)

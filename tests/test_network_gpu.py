@@ -456,6 +456,21 @@ def test_layer3_chained_tail_is_bit_identical_to_separate_launches(setup):
     assert torch.equal(fused, plain)
 
 
+def test_layer3_tail_kernel_variants_give_the_same_features(setup):
+    """option tail3_variant: 0 = bneck_tail3_kernel (consumer + helper waves), 1 (default) = bneck_tail3p_kernel (two-group pipeline),
+    2 = the same with 98-row LDS slots -- same features bit for bit."""
+    bb, x, *_ = setup
+    xd = x.to("cuda:0")
+    assert bb.get_option("tail3_variant") == 1
+    ref = bb.features(xd).clone()
+    try:
+        for v in (0, 2):
+            bb.set_option("tail3_variant", v)
+            assert torch.equal(bb.features(xd), ref), v
+    finally:
+        bb.set_option("tail3_variant", 1)
+
+
 def test_fp8_handover_in_the_conv_epilogue_is_bit_identical(setup_fp8):
     """fp8 mode: layer1's 16-bit output is quantised to e4m3 inside layer1.2.conv3's epilogue (same rounding sequence: 16-bit result,
     then x 1/scale, then e4m3) -- same features as with the separate quantisation pass, at batch sizes on both sides of the tile rule."""
@@ -471,3 +486,35 @@ def test_fp8_handover_in_the_conv_epilogue_is_bit_identical(setup_fp8):
         finally:
             bb.set_option("fuse_fp8_handover", 1)
         assert torch.equal(fused, plain), n
+
+
+def test_backbone_lanes_give_the_bits_of_one_backbone():
+    """backbone.BackboneLanes: two backbone copies on their own streams, batches dealt round robin -- the features of every batch are the
+    bits of a single backbone's, whatever lane it ran on and whatever else was in flight; the one-batch surface (``features``,
+    ``__call__``) is ordered with the current stream like ``ResNet50Backbone``'s."""
+    import torch
+    from implementation_phd_lab_vision_amd.backbone import BackboneLanes, ResNet50Backbone
+    from implementation_phd_lab_vision_amd.weights import synthetic_frames, synthetic_state_dict
+    dev = torch.device("cuda", 0)
+    sd = synthetic_state_dict(0)
+    one = ResNet50Backbone(state_dict=sd, max_batch=24).to(dev).eval()
+    two = BackboneLanes(lanes=2, state_dict=sd, max_batch=24).to(dev).eval()
+    try:
+        xs = [synthetic_frames(n, seed=900 + n).to(dev) for n in (24, 5, 17, 24, 9)]
+        refs = [one.features(x).clone() for x in xs]
+        torch.cuda.synchronize(dev)
+        tickets = [two.submit(x) for x in xs]              # five batches queued before the first result is looked at
+        assert [t.lane for t in tickets] == [0, 1, 0, 1, 0]
+        for t, r in zip(tickets, refs):
+            assert torch.equal(t.wait(), r)
+        # producer on the current stream, consumer on the current stream: no explicit events needed with features()
+        x = xs[2] * 1.0
+        y = two.features(x)
+        assert torch.equal(y, refs[2])
+        assert two(xs[1]).shape == (5, 2048, 1, 1)
+        two.set_option("tail3_variant", 0)
+        assert two.lane0.get_option("tail3_variant") == 0
+        two.set_option("tail3_variant", 1)
+    finally:
+        one.close()
+        two.close()
