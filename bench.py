@@ -208,6 +208,7 @@ def main() -> None:
     ap.add_argument("--no-block2", action="store_true", help="A/B: layer2.1-.3 as conv2 launch + fused tail instead of one launch per bottleneck body")
     ap.add_argument("--block1", type=int, default=-1, help="A/B: option fuse_block1 (0 = layer1 as conv2 launch + fused tail, 1 = layer1.1 in one launch, 2 = layer1.2 too: the default)")
     ap.add_argument("--inplace", action="store_true", help="A/B: plain-identity blocks write their output over their input (same bits; measured: no gain)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="A/B: any library option (r50_set_option), e.g. --opt tail3_bp=112")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true",
                     help="skip the batch-2 check forward behind the timed region (PMC passes: every profiled launch is then a full-batch one)")
@@ -293,6 +294,9 @@ def main() -> None:
         bb_opts.set_option("fuse_block2", 0)
     if args.block1 >= 0:
         bb_opts.set_option("fuse_block1", args.block1)
+    for kv in args.opt:
+        k_, v_ = kv.split("=", 1)
+        bb_opts.set_option(k_, int(v_))
     x = synthetic_frames(args.batch, seed=1234 + rank).to(dev)          # random data, resident in HBM
     run = bb.features
     if args.input == "u8":

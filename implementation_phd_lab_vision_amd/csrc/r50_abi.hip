@@ -784,10 +784,12 @@ hipError_t pack_tail3_weights(const void* w3, const void* w1, void* wp, hipStrea
 }
 // variant: 0 = bneck_tail3_kernel (4 consumer + 4 helper waves), 1 = bneck_tail3p_kernel (two-group pipeline, 112 LDS rows per slot),
 // 2 = the same with 98 rows per slot.  Default for the network: g_tail3_variant (env R50_TAIL3_VAR, option "tail3_variant").
+int g_tail3_bp = 0;        // option "tail3_bp": real pixels per tile of the chained layer3 tail (0 = whole rounds of the chip: 98 at batch 256)
 int g_tail3_variant = [] { const char* v = std::getenv("R50_TAIL3_VAR"); return v ? std::atoi(v) : 1; }();
 hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const float* b3, const void* res, void* out,
                               const float* b1, void* y1n, hipStream_t s, int et = 0, int bp_override = 0, int variant = -1) {
     if (variant < 0) variant = g_tail3_variant;
+    if (bp_override == 0) bp_override = g_tail3_bp;
     if (!y2 || !wp || !b3 || !res || !out || !b1 || !y1n || m <= 0 || m * 2048 >= (1ll << 31)) return hipErrorInvalidValue;
     if (g_num_cus == 0) {
         int dev = 0;
@@ -806,6 +808,10 @@ hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const
     long long bp = (m + rounds * g_num_cus - 1) / (rounds * g_num_cus);
     if (bp < 49) bp = 49;
     if (bp > rows) bp = rows;
+    // the pipelined kernel with more than one round of tiles: FULL tiles (batch 256: 448 tiles of 112 instead of 512 of 98 in 112 rows).  An
+    // eighth of the MFMA columns of a 98-pixel tile multiply padding; the ragged last round that full tiles leave is filled by the other
+    // lane's launches (bench.py --lanes 2: +0.9 % frames/s, two same-box pairs; neutral with one lane)
+    if (variant == 1 && (m + rows - 1) / rows > g_num_cus) bp = rows;
     if (bp_override >= 1 && bp_override <= rows) bp = bp_override;
     a.bp = (int)bp;
     a.n_tiles = (int)((m + bp - 1) / bp);
@@ -1739,6 +1745,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "fused_stem") h->fused_stem = value ? 1 : 0;
     else if (k == "fuse_tail") h->fuse_tail = value ? 1 : 0;
     else if (k == "fuse_tail3") h->fuse_tail3 = value ? 1 : 0;
+    else if (k == "tail3_bp") { if (value < 0 || value > 112) return fail(h, R50_ERR_INVALID, "tail3_bp must be 0 .. 112"); g_tail3_bp = (int)value; }
     else if (k == "tail3_variant") { if (value < 0 || value > 2) return fail(h, R50_ERR_INVALID, "tail3_variant must be 0, 1 or 2"); g_tail3_variant = (int)value; }
     else if (k == "fuse_fp8_handover") h->fuse_fp8_handover = value ? 1 : 0;
     else if (k == "fuse_stem_c1") h->fuse_stem_c1 = value ? 1 : 0;
@@ -1774,6 +1781,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "fuse_tail") *value = h->fuse_tail;
     else if (k == "fuse_tail3") *value = h->fuse_tail3;
     else if (k == "tail3_variant") *value = g_tail3_variant;
+    else if (k == "tail3_bp") *value = g_tail3_bp;
     else if (k == "fuse_fp8_handover") *value = h->fuse_fp8_handover;
     else if (k == "fuse_stem_c1") *value = h->fuse_stem_c1;
     else if (k == "fuse_ds_cat") *value = h->fuse_ds_cat;
