@@ -5,6 +5,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmcb_$C
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pmcb_$C -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --preheat 0 --no-check --dump-layers gpurun_out/pmcb_layers.json > gpurun_out/pmcb_$C.log 2>&1 || echo "pass $C failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pmcb_$C -- python3 bench.py --lanes 1 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --preheat 0 --no-check --dump-layers gpurun_out/pmcb_layers.json > gpurun_out/pmcb_$C.log 2>&1 || echo "pass $C failed"
 done
 python3 scripts/pmc_bench_summary.py --forwards 7 --layers gpurun_out/pmcb_layers.json --table gpurun_out/pmc_hbm_per_launch.txt > gpurun_out/pmc_hbm_traffic.json 2> gpurun_out/pmc_hbm_dropped.txt

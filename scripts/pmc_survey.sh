@@ -8,7 +8,7 @@ P3="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VME
 i=1
 for P in "$P1" "$P2" "$P3"; do
   rm -rf gpurun_out/pmcs_p$i
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d gpurun_out/pmcs_p$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --preheat 0 > gpurun_out/pmcs_p$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d gpurun_out/pmcs_p$i -- python3 bench.py --lanes 1 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --preheat 0 > gpurun_out/pmcs_p$i.log 2>&1 || echo "pass $i failed"
   i=$((i+1))
 done
 python3 scripts/pmc_survey_summary.py > gpurun_out/pmc_survey.txt
