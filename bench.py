@@ -489,7 +489,7 @@ def main() -> None:
         t3 = prof.get("bneck_tail3")
         if t3 and t3["ms"] > 0:       # the chained layer3 tails (conv3 + identity + ReLU + next conv1): both MFMA work and HBM streaming
             t3_traffic = (tdata.get("bneck_tail3") or {}).get("hbm_bytes_per_launch")
-            roofline["third_kernel"] = {"kernel": "bneck_tail3_kernel (%d launches/step)" % round(t3["launches"] / max(1, args.steps)),
+            roofline["third_kernel"] = {"kernel": "bneck_tail3p_kernel (chained layer3 tail, two-group pipeline; %d launches/step)" % round(t3["launches"] / max(1, args.steps)),
                                         "traffic": t3_traffic, "traffic_source": traffic_source, "algorithmic_bytes": t3["bytes"] / max(1, t3["launches"]),
                                         "avg_launch_us": 1e3 * t3["ms"] / max(1, t3["launches"]),
                                         "tflops": t3["flops"] / (t3["ms"] * 1e-3) / 1e12, "frac_of_mfma_peak": t3["flops"] / (t3["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
