@@ -254,3 +254,5 @@ def test_bench_under_torchrun_runs_gather_barrier_and_fence_on_rccl(tmp_path, li
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["value"] > 1000 and rec["checked"]["finite"] and rec["checked"]["equal_to_batch2_run"]
     assert "RCCL gather" in rec["config"]["workload"]
+    # the default two lanes: step k's gather waits for lane k % 2's event, the lane's next step for the event behind that gather
+    assert rec["config"]["lanes"] == 2 and rec["checked"]["lanes_equal"] is True
