@@ -205,6 +205,7 @@ def main() -> None:
     ap.add_argument("--no-stem-c1", action="store_true", help="A/B: layer1.0.conv1 as its own igemm launch instead of inside the stem kernel")
     ap.add_argument("--no-ds-cat", action="store_true", help="A/B: downsample conv and conv3 of layer2.0 / 3.0 / 4.0 as separate launches")
     ap.add_argument("--no-overlap-ds", action="store_true", help="A/B: downsample convs on the main stream")
+    ap.add_argument("--no-cat-chain", action="store_true", help="A/B: layer2.0's conv3 + downsample launch and layer2.1.conv1 as two igemm launches")
     ap.add_argument("--no-block2", action="store_true", help="A/B: layer2.1-.3 as conv2 launch + fused tail instead of one launch per bottleneck body")
     ap.add_argument("--block1", type=int, default=-1, help="A/B: option fuse_block1 (0 = layer1 as conv2 launch + fused tail, 1 = layer1.1 in one launch, 2 = layer1.2 too: the default)")
     ap.add_argument("--inplace", action="store_true", help="A/B: plain-identity blocks write their output over their input (same bits; measured: no gain)")
@@ -292,6 +293,8 @@ def main() -> None:
         bb_opts.set_option("inplace_out", 1)
     if args.no_block2:
         bb_opts.set_option("fuse_block2", 0)
+    if args.no_cat_chain:
+        bb_opts.set_option("fuse_cat_chain", 0)
     if args.block1 >= 0:
         bb_opts.set_option("fuse_block1", args.block1)
     for kv in args.opt:
@@ -494,6 +497,13 @@ def main() -> None:
                                         "avg_launch_us": 1e3 * t3["ms"] / max(1, t3["launches"]),
                                         "tflops": t3["flops"] / (t3["ms"] * 1e-3) / 1e12, "frac_of_mfma_peak": t3["flops"] / (t3["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                         "GBps": t3["bytes"] / (t3["ms"] * 1e-3) / 1e9, "frac_of_hbm_peak": t3["bytes"] / (t3["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        cc = prof.get("bneck_catchain")
+        if cc and cc["ms"] > 0:       # layer2.0's transition tail (conv3 + downsample as one two-source conv) chained with layer2.1.conv1
+            roofline["fifth_kernel"] = {"kernel": "bneck_catchain_kernel (layer2.0 conv3 + downsample + ReLU chained with layer2.1.conv1; %d launches/step)" % round(cc["launches"] / max(1, args.steps)),
+                                        "traffic": (tdata.get("bneck_catchain") or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_source,
+                                        "algorithmic_bytes": cc["bytes"] / max(1, cc["launches"]), "avg_launch_us": 1e3 * cc["ms"] / max(1, cc["launches"]),
+                                        "tflops": cc["flops"] / (cc["ms"] * 1e-3) / 1e12, "frac_of_mfma_peak": cc["flops"] / (cc["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                        "GBps": cc["bytes"] / (cc["ms"] * 1e-3) / 1e9, "frac_of_hbm_peak": cc["bytes"] / (cc["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         b2 = prof.get("bneck_block2")
         if b2 and b2["ms"] > 0:       # layer2.1-.3 bottleneck bodies in one launch each: MFMA work and HBM streaming at once
             b_traffic = None
@@ -513,7 +523,7 @@ def main() -> None:
                 {"name": k, "launches_per_step": prof[k]["launches"] / args.steps, "bytes_per_launch": prof[k]["bytes"] / max(1, prof[k]["launches"]),
                  "flops_per_launch": prof[k]["flops"] / max(1, prof[k]["launches"]), "us_per_launch": 1e3 * prof[k]["ms"] / max(1, prof[k]["launches"])}
                 for k in order], indent=1))
-        classes = ("igemm", "bneck_tail", "bneck_tail3", "bneck_block2", "conv1", "maxpool", "avgpool", "stem_pack")
+        classes = ("igemm", "bneck_tail", "bneck_tail3", "bneck_block2", "bneck_catchain", "conv1", "maxpool", "avgpool", "stem_pack")
         tot_ms = sum(prof[k]["ms"] for k in classes if k in prof)
         kernels = {k: {"launches_per_step": prof[k]["launches"] / args.steps, "ms_per_step": prof[k]["ms"] / args.steps,
                        "share": prof[k]["ms"] / tot_ms if tot_ms else 0.0} for k in classes if k in prof and prof[k]["launches"]}

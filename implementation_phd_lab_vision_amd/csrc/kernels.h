@@ -3229,6 +3229,346 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bneck_catchain_kernel (round 3): the TRANSITION tail of layer2.0 -- conv3 + downsample + add + ReLU as one 1x1 conv over
+// K = [t2 (128 channels) | block input sampled at stride 2 (256 channels)] against [W3 | Wd] (the two-source GEMM of igemm_ws_kernel),
+// CHAINED with the next block's conv1 (512 -> 128) + ReLU, in the two-group pipeline of bneck_tail3p_kernel:
+//   * the tile's K operand -- 112 pixels x 384 channels = 6 K-slots of 14 KB -- is RESIDENT in LDS (t2 rows in slots 0-1, the strided
+//     rows of the block input in slots 2-5; 256 -> 512 has no identity tensor, so group A's queue carries only its weight stream);
+//   * group A (waves 0-3): per 128-channel chunk c of the block output six weight steps (K-slots 0..5 of Wcat[c]) from bias b3 + bd, then
+//     E(c): ReLU, 16 bit -> out_c[c & 1];  group B (waves 4-7), one chunk behind: two weight steps of W1[:, c] against out_c into the
+//     next conv1's accumulators (32 couts x 112 pixels per wave), then the copy-out of out_c with full-row stores; y1n after chunk 3;
+//   * one barrier per chunk, a fifth interval per tile in which the next tile's operand rows land.
+// Summation orders are those of the two igemm launches (bias first, K ascending over [t2 | x], ReLU; b1 first, K ascending): same bits.
+// At batch 256: 1792 tiles = exactly 7 per CU.  LDS: 6 + 4 slots of 112 rows x 128 B + b1 + b3 = 145,920 B.
+// Weights: catchain_pack_kernel's stream [chunk 4][step 8: Wcat K-slot 0..5, W1 K-slot 0..1][wave 4][fragment 4][lane 64] x 16 B = 512 KB.
+// ------------------------------------------------------------------------------------------------
+struct CatChainArgs {
+    const __bf16* t2;     // (M, 128)        conv2 output
+    const __bf16* x;      // (N, 2 OW, 2 OW, 256)  block input
+    const __bf16* wp;     // packed weights (catchain_pack_kernel)
+    const float* b3;      // (512)   b3 + bd
+    __bf16* out;          // (M, 512)        block output
+    const float* b1;      // (128)
+    __bf16* y1n;          // (M, 128)        next block's conv1 output
+    int M;                // N * OW * OW
+    int bp;               // real pixels per tile (<= 112)
+    int n_tiles;
+    unsigned x_bytes;     // N * 4 OW OW * 512
+#if defined(R50_STAMP)
+    unsigned long long* dbg;
+#endif
+};
+
+// (512, 384) [W3 | Wd] and (128, 512) next-conv1 weights, K contiguous -> the fragment-ordered stream (see tail3_pack_kernel)
+__global__ void catchain_pack_kernel(const __bf16* __restrict__ wcat, const __bf16* __restrict__ w1, __bf16* __restrict__ wp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // one 16-B element each; 4 * 8 * 4 * 4 * 64 = 32,768
+    if (idx >= 32768) return;
+    const int lane = idx & 63, f = (idx >> 6) & 3, w = (idx >> 8) & 3, st = (idx >> 10) & 7, c = idx >> 13;
+    const int fr = lane & 15, fq = lane >> 4, m = f >> 1, kk = f & 1;
+    const int rho = 32 * w + 16 * m + fr;
+    const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
+    const __bf16* src;
+    if (st < 6) src = wcat + (size_t)(c * 128 + cl) * 384 + st * 64 + kk * 32 + fq * 8;
+    else src = w1 + (size_t)cl * 512 + c * 128 + (st - 6) * 64 + kk * 32 + fq * 8;
+    reinterpret_cast<u32x4*>(wp)[idx] = *reinterpret_cast<const u32x4*>(src);
+}
+
+#ifndef CC_ABL            // diagnostic ablations (timing only): 2 = no HBM stores, 4 = no MFMAs
+#define CC_ABL 0
+#endif
+#ifndef CC_PRIO           // 1 = group B at s_setprio 1 (its two steps per chunk then finish early and its copy-out / operand issue run beside group A's six)
+#define CC_PRIO 0
+#endif
+#ifndef CC_WDA            // group A's weight prefetch distance in steps: 2 or 4
+#define CC_WDA 4
+#endif
+#ifndef CC_PD             // LDS prefetch depth (pixel fragments) of a weight step
+#define CC_PD 6
+#endif
+template <int ET, int OW>
+__global__ __launch_bounds__(512) void bneck_catchain_kernel(const CatChainArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int CT2 = 128, CX = 256, COUT = 512, C1N = 128;
+    constexpr int KSA = (CT2 + CX) / 64;          // resident K-slots
+    constexpr int NCH = COUT / 128;               // chunks of 128 block-output channels
+    constexpr int NR = 7, ROWS = 112;
+    constexpr int SLOT = ROWS * 128;
+    constexpr int XR = 0, OUTC = KSA * SLOT, B1_OFF = OUTC + 4 * SLOT, B3_OFF = B1_OFF + C1N * 4, SYNC_OFF = B3_OFF + COUT * 4;
+    constexpr int OC_PASSES = 2 * ROWS / 32;      // 7
+    constexpr int HOWO = OW * OW, WI = 2 * OW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wave & 3;
+    const int lt = tid & 255, srow = lt >> 3;
+    const int grid = gridDim.x;
+    const int first = blockIdx.x;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    if (tid < C1N) reinterpret_cast<float*>(smem + B1_OFF)[tid] = a.b1[tid];
+    reinterpret_cast<float*>(smem + B3_OFF)[tid] = a.b3[tid];         // 512 threads, 512 biases
+    if (tid < 4) reinterpret_cast<unsigned*>(smem + SYNC_OFF)[tid] = 0u;    // REL[0..2], LAND (see below)
+
+    const __amdgpu_buffer_rsrc_t rs_wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wp), 0, 524288u, 0x00020000);
+    const unsigned wp_voff = (unsigned)(lane * 16 + w * 4096);
+    const int fphys0 = (fq ^ (fr & 7)) << 4;
+    const int x_frag = fr * 128;
+    auto w_load_half = [&](int sofs, bf16x8 (&wf)[4], int kk) {       // sofs: scalar byte offset of the (chunk, step) slice
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+            wf[2 * m + kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wp, wp_voff + (2 * m + kk) * 1024, sofs, 0));
+    };
+    // one weight step (see bneck_tail3p_kernel); `sofs_next`: the slice this step's buffer is re-requested for
+    auto w_step = [&](int sofs_next, bf16x8 (&wf)[4], const char* xb, f32x4 (&acc0)[NR], f32x4 (&acc1)[NR]) {
+        constexpr int NS = 2 * NR, PD = CC_PD;
+        bf16x8 x[NS];
+        auto xread = [&](int t) { return *reinterpret_cast<const bf16x8*>(xb + x_frag + (t % NR) * 2048 + (t >= NR ? (fphys0 ^ 64) : fphys0)); };
+#pragma unroll
+        for (int t = 0; t < PD; ++t) x[t] = xread(t);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int j = t % NR, kk = t / NR;
+            if constexpr (CC_ABL & 4) { asm volatile("" ::"v"(wf[kk]), "v"(wf[2 + kk]), "v"(x[t])); }
+            else {
+                acc0[j] = mfma_e<ET>(wf[kk], x[t], acc0[j]);
+                acc1[j] = mfma_e<ET>(wf[2 + kk], x[t], acc1[j]);
+            }
+            if (t + PD < NS) x[t + PD] = xread(t + PD);
+            if (t == NR - 1) w_load_half(sofs_next, wf, 0);
+        }
+        w_load_half(sofs_next, wf, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (t + PD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (t == NR - 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);        // a scheduling region per step
+    };
+    auto sofs_of = [&](int c, int st) { return __builtin_amdgcn_readfirstlane(((c & (NCH - 1)) * 8 + st) << 14); };
+    // The NEXT tile's operand rows are fetched while this tile's last chunk is still running (a fifth, load-only interval per tile cost 40 %
+    // of the first version: every CU fetched its 84 KB at the same moment with nothing else to do).  K-slot pairs {0,1} {2,3} {4,5} are
+    // released one by one as group A's waves finish reading them in the tile's last chunk -- REL[g] counts those waves -- and group B (whose
+    // weight stream runs a whole chunk ahead, so HBM latencies in its in-order vmcnt queue stall nothing) re-fills each pair as soon as its
+    // count is complete.  Pairs 0 and 1 have landed before the chunk barrier; pair 2 lands during the next interval: LAND counts the
+    // group-B waves whose pieces are in, and group A looks at it before the next tile's first step on slot 4.
+    LDS_AS unsigned* const sync = (LDS_AS unsigned*)(smem + SYNC_OFF);        // (explicit LDS address space: ds_read / ds_add, no generic-pointer casts)
+    auto spin_until = [&](int word, unsigned target) {
+        while (__hip_atomic_load(sync + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");            // nothing that follows (fragment reads, LDS-DMA issue) moves above the poll
+    };
+    auto signal = [&](int word) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the wave's own reads of the released slots have returned
+        if (lane == 0) (void)__hip_atomic_fetch_add(sync + word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    bf16x8 wA[4], wB[4];
+
+    if (wave < 4) {
+        // =============================== group A: [W3 | Wd] . [t2 ; x] + ReLU -> out_c ==============
+        const int c_frag = (w >> 1) * SLOT + x_frag + (((4 * (w & 1) + fq) ^ (fr & 7)) << 4);
+        f32x4 accA[2][NR];
+        // weight fragments CC_WDA steps ahead (4: a ring of four register buffers, step g in buffer g % 4 -- six steps per chunk, so the buffer
+        // of a step alternates with the chunk's parity and the chunk loop is unrolled by two; 2: two buffers).  With two steps of cover
+        // (8 KB per wave in flight) every step waited for its weights: L2 under this load answers in ~2,000 cycles, a step issues in ~450.
+        bf16x8 wq[4][4];
+#pragma unroll
+        for (int q = 0; q < CC_WDA; ++q) { w_load_half(sofs_of(0, q), wq[q], 0); w_load_half(sofs_of(0, q), wq[q], 1); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // own bias / sync words written
+        __builtin_amdgcn_s_barrier();             // P: biases, sync words and the first tile's operand rows (group B) are in LDS
+        unsigned tl = 0;                          // tiles this workgroup has finished
+        R50_STAMP_DECL
+        auto chunk_a = [&](auto par_c, int c) {
+            constexpr int PAR = decltype(par_c)::value;           // chunk parity: its step 0 sits in ring buffer (6 PAR) % CC_WDA
+            constexpr int B0 = (6 * PAR) % CC_WDA;
+            {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + B3_OFF + (c * 128 + 32 * w + 8 * fq) * 4);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + B3_OFF + (c * 128 + 32 * w + 8 * fq + 4) * 4);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) { accA[0][j] = lo; accA[1][j] = hi; }
+            }
+            const bool last = (c == NCH - 1);
+            // the slice step s's buffer is re-requested for: step s + CC_WDA of the stream
+            auto nxt = [&](int st) { return st + CC_WDA < 6 ? sofs_of(c, st + CC_WDA) : sofs_of(c + 1, st + CC_WDA - 6); };
+            w_step(nxt(0), wq[(B0 + 0) % CC_WDA], smem + XR + 0 * SLOT, accA[0], accA[1]);
+            w_step(nxt(1), wq[(B0 + 1) % CC_WDA], smem + XR + 1 * SLOT, accA[0], accA[1]);
+            if (last) signal(0);
+            w_step(nxt(2), wq[(B0 + 2) % CC_WDA], smem + XR + 2 * SLOT, accA[0], accA[1]);
+            w_step(nxt(3), wq[(B0 + 3) % CC_WDA], smem + XR + 3 * SLOT, accA[0], accA[1]);
+            if (last) signal(1);
+            if (c == 0) spin_until(3, 4u * tl);                     // slots 4 / 5 of THIS tile have landed (trivially true for the first tile)
+            R50_MARK(5)                           // steps 0-3 (+ the poll of the late operand pair)
+            w_step(nxt(4), wq[(B0 + 4) % CC_WDA], smem + XR + 4 * SLOT, accA[0], accA[1]);
+            w_step(nxt(5), wq[(B0 + 5) % CC_WDA], smem + XR + 5 * SLOT, accA[0], accA[1]);
+            if (last) signal(2);
+#if defined(R50_STAMP)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 0" ::"v"(accA[1][NR - 1]), "v"(accA[0][NR - 1]) : "memory");
+#endif
+            R50_MARK(0)                           // steps 4-5
+            __builtin_amdgcn_sched_barrier(0);
+            char* ob = smem + OUTC + PAR * 2 * SLOT + c_frag;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const f32x4 lo = accA[0][j], hi = accA[1][j];
+                u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                *reinterpret_cast<u32x4*>(ob + j * 2048) = o;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // out_c written before anybody reads it
+            R50_MARK(1)                           // E
+            __builtin_amdgcn_s_barrier();
+            R50_MARK(2)                           // chunk barrier
+        };
+        for (int tile = first; tile < a.n_tiles; tile += grid, ++tl) {
+            for (int c2 = 0; c2 < NCH / 2; ++c2) {
+                chunk_a(std::integral_constant<int, 0>{}, 2 * c2);
+                chunk_a(std::integral_constant<int, 1>{}, 2 * c2 + 1);
+            }
+        }
+        __builtin_amdgcn_s_barrier();             // the interval in which group B finishes the last chunk
+        R50_STAMP_FLUSH(8)
+    } else {
+        // =============================== group B: next conv1 + copy-out + the next tile's operand rows =
+        const __amdgpu_buffer_rsrc_t rs_t2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.t2), 0, (unsigned)a.M * (CT2 * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, a.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.M * (C1N * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.M * (COUT * 2u), 0x00020000);
+        // Operand rows: row R = 32 i + srow of the [6 slots][112] region: slot R / 112 (wave-uniform: 112 is a multiple of the 8 rows of a wave's
+        // piece), pixel row (32 i + srow) % 112 = one of SEVEN values per lane (32 i mod 112 has period 7).  Per tile and value: the lane's byte offset
+        // in t2 and in the block input (pixel (n, ho, wo) reads input pixel (n, 2 ho, 2 wo)), chunk swizzle included; slot offsets are scalar.
+        // Passes 0-6 fill slots 0-1, 7-13 slots 2-3, 14-20 slots 4-5.
+        unsigned vt[7], vx[7];
+        auto x_rows = [&](int tile) {
+            const int p0 = tile * a.bp;
+            const int limit = (tile < a.n_tiles) ? ((a.M - p0 < a.bp) ? a.M - p0 : a.bp) : 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const int prow = (32 * k + srow) % ROWS;
+                const int lchunk = (lt & 7) ^ (prow & 7);
+                const unsigned p = (unsigned)(p0 + prow);
+                const unsigned n = p / HOWO, r = p - n * HOWO, ho = r / OW, wo = r - ho * OW;
+                const unsigned q = (n * WI + 2 * ho) * WI + 2 * wo;
+                const bool ok = prow < limit;
+                vt[k] = ok ? (p * CT2 + lchunk * 8) * 2u : kOobOffset;
+                vx[k] = ok ? (q * CX + lchunk * 8) * 2u : kOobOffset;
+            }
+        };
+        auto issue_x = [&](auto grp_c) {          // the 7 passes of slot pair GRP
+            constexpr int GRP = decltype(grp_c)::value;
+#pragma unroll
+            for (int i = 7 * GRP; i < 7 * GRP + 7; ++i) {
+                const int sl = __builtin_amdgcn_readfirstlane((32 * i + 8 * w) / ROWS);
+                char* dst = smem + XR + i * 4096 + w * 1024;
+                if (GRP == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t2, (LDS_AS void*)dst, 16, vt[i % 7], sl * 128, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)dst, 16, vx[i % 7], (sl - 2) * 128, 0, 0);
+            }
+        };
+        using G0 = std::integral_constant<int, 0>;
+        using G1 = std::integral_constant<int, 1>;
+        using G2 = std::integral_constant<int, 2>;
+        f32x4 accB[2][NR];
+        unsigned rvo[OC_PASSES];
+        auto out_rows = [&](int tile) {
+            const int p0 = tile * a.bp;
+            const int limit = (a.M - p0 < a.bp) ? a.M - p0 : a.bp;
+#pragma unroll
+            for (int i = 0; i < OC_PASSES; ++i) {
+                const int R = 32 * i + srow;
+                const int sl = R / ROWS, prow = R - ROWS * sl;
+                const int lchunk = (lt & 7) ^ (prow & 7);
+                rvo[i] = (prow < limit) ? (unsigned)((p0 + prow) * COUT + sl * 64 + lchunk * 8) * 2u : kOobOffset;
+            }
+        };
+        auto y1n_store = [&](int tile) {
+            const int p0 = tile * a.bp;
+            const int limit = (a.M - p0 < a.bp) ? a.M - p0 : a.bp;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const f32x4 lo = accB[0][j], hi = accB[1][j];
+                u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
+                const unsigned voff = (16 * j + fr < limit) ? (unsigned)((p0 + 16 * j + fr) * C1N + 32 * w + 8 * fq) * 2u : kOobOffset;
+                if (!(CC_ABL & 2) || o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, voff, 0, 0);
+            }
+        };
+        auto init_accb = [&]() {                  // accB[e]: channels 32w + 8fq + 4e ..
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + B1_OFF + (32 * w + 8 * fq) * 4);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + B1_OFF + (32 * w + 8 * fq + 4) * 4);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) { accB[0][j] = lo; accB[1][j] = hi; }
+        };
+        x_rows(first);
+        issue_x(G0{}); issue_x(G1{}); issue_x(G2{});
+        w_load_half(sofs_of(0, 6), wA, 0); w_load_half(sofs_of(0, 6), wA, 1);
+        w_load_half(sofs_of(0, 7), wB, 0); w_load_half(sofs_of(0, 7), wB, 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // own operand pieces landed, own bias words written
+        __builtin_amdgcn_s_barrier();             // P
+        if (CC_PRIO & 1) __builtin_amdgcn_s_setprio(1);
+        init_accb();
+        __builtin_amdgcn_s_barrier();             // first interval: group A is on chunk 0 of its first tile
+        unsigned tl = 0;
+        R50_STAMP_DECL
+        for (int tile = first; tile < a.n_tiles; tile += grid, ++tl) {
+            out_rows(tile);
+            for (int c = 0; c < NCH; ++c) {       // (group A is on chunk c + 1: for c = 3 that is the next tile's chunk 0)
+                const char* xb = smem + OUTC + (c & 1) * 2 * SLOT;
+                if (c == NCH - 2) x_rows(tile + grid);
+                w_step(sofs_of(c + 1, 6), wA, xb, accB[0], accB[1]);
+                R50_MARK(2)                       // B: weight step 0
+                if (c == NCH - 2) { spin_until(0, 4u * (tl + 1)); issue_x(G0{}); }
+                R50_MARK(5)                       // release wait + operand issue
+                if (c == NCH - 1) {               // the late pair of the tile group A has just started: landed behind the 4 weight loads of that step
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    signal(3);
+                }
+                R50_MARK(6)                       // late pair landing wait + signal
+                w_step(sofs_of(c + 1, 7), wB, xb + SLOT, accB[0], accB[1]);
+                R50_MARK(2)                       // B: weight step 1
+                if (c == NCH - 2) { spin_until(1, 4u * (tl + 1)); issue_x(G1{}); }
+                R50_MARK(5)
+#if defined(R50_STAMP)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 0" ::"v"(accB[1][NR - 1]), "v"(accB[0][NR - 1]) : "memory");
+#endif
+                R50_MARK(2)                       // B: 2 weight steps (+ operand issue)
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const int cofs = __builtin_amdgcn_readfirstlane(c * 256);
+                    u32x4 v[OC_PASSES];
+#pragma unroll
+                    for (int i = 0; i < OC_PASSES; ++i) v[i] = *reinterpret_cast<const u32x4*>(xb + i * 4096 + lt * 16);
+#pragma unroll
+                    for (int i = 0; i < OC_PASSES; ++i)
+                        if (!(CC_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, rvo[i], cofs, 0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                R50_MARK(3)                       // copy-out
+                if (c == NCH - 2) {
+                    spin_until(2, 4u * (tl + 1));
+                    issue_x(G2{});
+                    R50_MARK(5)
+                    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");     // pairs 0 and 1 have landed (younger: 7 stores, 7 pieces of pair 2)
+                    R50_MARK(6)
+                }
+                if (c == NCH - 1) { y1n_store(tile); init_accb(); }
+                R50_MARK(0)                       // late pair issue / y1n
+                __builtin_amdgcn_s_barrier();
+                R50_MARK(4)                       // chunk barrier
+            }
+        }
+        R50_STAMP_FLUSH(8)
+    }
+#else
+    (void)a;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Bottleneck BODY (layer2.1-.3), one launch per block: conv2 3x3 (128 -> 128) + bn2 + ReLU, conv3 1x1 (128 -> 512) + bn3 + identity +
 // ReLU and -- C1N = 128 -- the NEXT block's conv1 1x1 (512 -> 128) + bn1 + ReLU (src/preprocess_resnet_features.py:296 -> torchvision
 // Bottleneck.forward, restated in oracle/resnet50_oracle.py).

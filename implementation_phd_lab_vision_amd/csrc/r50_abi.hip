@@ -22,8 +22,8 @@ struct Prof {
     int64_t launches = 0;
     double ms = 0, flops = 0, bytes = 0;
 };
-enum ProfClass { PC_IGEMM = 0, PC_STEM_CONV, PC_MAXPOOL, PC_AVGPOOL, PC_STEM_PACK, PC_TAIL, PC_TAIL3, PC_BLOCK2, PC_COUNT };
-const char* kProfNames[PC_COUNT] = {"igemm", "conv1", "maxpool", "avgpool", "stem_pack", "bneck_tail", "bneck_tail3", "bneck_block2"};
+enum ProfClass { PC_IGEMM = 0, PC_STEM_CONV, PC_MAXPOOL, PC_AVGPOOL, PC_STEM_PACK, PC_TAIL, PC_TAIL3, PC_BLOCK2, PC_CATCHAIN, PC_COUNT };
+const char* kProfNames[PC_COUNT] = {"igemm", "conv1", "maxpool", "avgpool", "stem_pack", "bneck_tail", "bneck_tail3", "bneck_block2", "bneck_catchain"};
 
 struct EvRec {
     hipEvent_t a, b;
@@ -68,6 +68,8 @@ struct r50_handle {
     int fuse_tail = 1;                  // bf16 mode, layer1: conv3 + identity + ReLU + the next block's conv1 in one kernel
     int fuse_fp8_handover = 1;          // fp8 mode: quantise layer1's output in layer1.2.conv3's epilogue instead of in a pass of its own
     int fuse_tail3 = 1;                 // layer3.1-.4: conv3 + identity + ReLU chained with the next block's conv1 through LDS (bneck_tail3_kernel)
+    __bf16* catchain_wp = nullptr;      // layer2.0: [W3 | Wd] and layer2.1.conv1 in bneck_catchain_kernel's fragment-ordered stream
+    int fuse_cat_chain = 1;             // layer2.0: conv3 + downsample + ReLU chained with layer2.1.conv1 in one launch (bneck_catchain_kernel)
     __bf16* tail3_wp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per layer3 block b: [W3(b) | W1(b+1)] in the kernel's fragment order
     int fuse_block1 = 2;                // 1: layer1.1, 2 (default since round 3: with the loaders' position loop unrolled the c1 = 128 form takes 248 us against
                                         // 276 for conv2 + fused tail): also layer1.2 -- the bottleneck body in one launch (bneck_block1_kernel)
@@ -834,6 +836,46 @@ hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const
     return hipGetLastError();
 }
 
+// layer2.0 transition tail: conv3 + downsample (one conv over K = [t2 | x at stride 2]) + ReLU chained with the next block's conv1
+// (kernels.h: bneck_catchain_kernel).  `wp`: both weight matrices in the kernel's fragment-ordered stream (512 KB; pack_catchain_weights).
+constexpr size_t kCatChainPackedBytes = 1u << 19;
+hipError_t pack_catchain_weights(const void* wcat, const void* w1, void* wp, hipStream_t s) {
+    if (!wcat || !w1 || !wp) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(catchain_pack_kernel, dim3(32768 / 256), dim3(256), 0, s, (const __bf16*)wcat, (const __bf16*)w1, (__bf16*)wp);
+    return hipGetLastError();
+}
+hipError_t launch_bneck_catchain(const void* t2, const void* x, int n, int ow, const void* wp, const float* bcat, void* out,
+                                 const float* b1, void* y1n, hipStream_t s, int et = 0) {
+    if (!t2 || !x || !wp || !bcat || !out || !b1 || !y1n || n <= 0 || ow != 28) return hipErrorInvalidValue;
+    const long long m = (long long)n * ow * ow;
+    if (m * 1024 >= (1ll << 31) || (long long)n * 4 * ow * ow * 512 >= (1ll << 31)) return hipErrorInvalidValue;
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        g_num_cus = cu_budget(prop.multiProcessorCount);
+    }
+    CatChainArgs a;
+    a.t2 = (const __bf16*)t2; a.x = (const __bf16*)x; a.wp = (const __bf16*)wp; a.b3 = bcat; a.out = (__bf16*)out; a.b1 = b1; a.y1n = (__bf16*)y1n;
+    a.M = (int)m; a.x_bytes = (unsigned)((long long)n * 4 * ow * ow * 512);
+#if defined(R50_STAMP)
+    a.dbg = g_dbg;
+#endif
+    // full 112-pixel tiles when there is more than one round of them (batch 256: 1792 tiles = 7 per CU), else spread over the chip
+    const long long full = (m + 111) / 112;
+    long long bp = 112;
+    if (full <= g_num_cus) { bp = (m + g_num_cus - 1) / g_num_cus; if (bp < 16) bp = 16; if (bp > 112) bp = 112; }
+    a.bp = (int)bp;
+    a.n_tiles = (int)((m + bp - 1) / bp);
+    const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
+    const size_t lds = 10 * 112 * 128 + 128 * 4 + 512 * 4 + 16;        // operand slots + out_c + b1 + b3 + 4 sync words
+    auto kern = et == 1 ? bneck_catchain_kernel<1, 28> : bneck_catchain_kernel<0, 28>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 // layer2.1-.3 bottleneck body in one launch (kernels.h: bneck_block2_kernel): conv2 + conv3 + identity + ReLU [+ the next block's conv1]
 hipError_t launch_bneck_block2(const void* t1, int n, const void* w2, const float* b2, const void* w3, const float* b3, const void* res,
                                void* out, const void* w1, const float* b1, void* y1n, hipStream_t s, int et = 0) {
@@ -1373,6 +1415,20 @@ after_pool:
                 if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_tail launch (" + c3.conv_key + "): " + hipGetErrorString(e));
                 h3 = h2; w3 = w2;
                 pre_t1 = fr[0];
+            } else if (cat_ds && h->fuse_cat_chain && h->catchain_wp && si == 1 && fuse_ok && !tap && h2 == 28 && w2 == 28 && hh == 56 && ww == 56 &&
+                       (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16) && c3.cin == 128 && c3.cout == 512 && cdp->cin == 256 &&
+                       cdp->stride == 2 && nx->cin == 512 && nx->cout == 128) {
+                // layer2.0: the two-source conv3 + downsample GEMM chained with layer2.1.conv1 through LDS (kernels.h: bneck_catchain_kernel);
+                // same bits as the two-source igemm launch followed by the 1x1 launch
+                const double m = (double)n * 784.0;
+                EvRec rt{};
+                prof_begin(h, s, rt, PC_CATCHAIN, 2.0 * m * (512.0 * 384 + 128.0 * 512), 2.0 * (m * (128.0 + 256 + 512 + 128) + 512.0 * 384 + 128.0 * 512),
+                           (int)(&c3 - &h->convs[0]));
+                e = launch_bneck_catchain(buf[fr[1]], buf[cur], n, 28, h->catchain_wp, h->cat_bias[1], outb, nx->bias, buf[fr[0]], s, et);
+                prof_end(h, s, rt);
+                if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_catchain launch (" + c3.conv_key + "): " + hipGetErrorString(e));
+                h3 = h2; w3 = w2;
+                pre_t1 = fr[0];
             } else if (cat_ds) {
                 rc = run_conv_cat(h, si, c3, *cdp, buf[fr[1]], buf[cur], n, h2, w2, hh, ww, outb, s);
                 if (rc) return rc;
@@ -1408,6 +1464,7 @@ void free_all(r50_handle* h) {
         L.w = nullptr; L.bias = nullptr; L.bias_scaled = nullptr;
     }
     for (auto& p : h->tail3_wp) { if (p) (void)hipFree(p); p = nullptr; }
+    if (h->catchain_wp) { (void)hipFree(h->catchain_wp); h->catchain_wp = nullptr; }
     for (int i = 0; i < 4; ++i) {
         if (h->cat_w[i]) (void)hipFree(h->cat_w[i]);
         if (h->cat_bias[i]) (void)hipFree(h->cat_bias[i]);
@@ -1634,6 +1691,16 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
             const int blocks = kStages[si][1];
             for (int b = 0; b < blocks; ++b) {
                 const size_t i3 = li + 2, inx = li + ((b == 0) ? 4 : 3);
+                if (si == 1 && b == 0 && h->cat_w[1] && inx < h->convs.size()) {
+                    const ConvLayer& c3 = h->convs[i3];
+                    const ConvLayer& cd = h->convs[li + 3];
+                    const ConvLayer& nx = h->convs[inx];
+                    if (c3.ks == 1 && c3.cin == 128 && c3.cout == 512 && cd.ks == 1 && cd.cin == 256 && cd.stride == 2 && nx.ks == 1 && nx.stride == 1 &&
+                        nx.cin == 512 && nx.cout == 128) {
+                        if (!h->catchain_wp) HIP_TRY(h, hipMalloc((void**)&h->catchain_wp, kCatChainPackedBytes));
+                        HIP_TRY(h, pack_catchain_weights(h->cat_w[1], nx.w, h->catchain_wp, nullptr));
+                    }
+                }
                 if (si == 2 && b > 0 && b < 8 && inx < h->convs.size()) {
                     const ConvLayer& c3 = h->convs[i3];
                     const ConvLayer& nx = h->convs[inx];
@@ -1745,6 +1812,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "fused_stem") h->fused_stem = value ? 1 : 0;
     else if (k == "fuse_tail") h->fuse_tail = value ? 1 : 0;
     else if (k == "fuse_tail3") h->fuse_tail3 = value ? 1 : 0;
+    else if (k == "fuse_cat_chain") h->fuse_cat_chain = value ? 1 : 0;
     else if (k == "tail3_bp") { if (value < 0 || value > 112) return fail(h, R50_ERR_INVALID, "tail3_bp must be 0 .. 112"); g_tail3_bp = (int)value; }
     else if (k == "tail3_variant") { if (value < 0 || value > 2) return fail(h, R50_ERR_INVALID, "tail3_variant must be 0, 1 or 2"); g_tail3_variant = (int)value; }
     else if (k == "fuse_fp8_handover") h->fuse_fp8_handover = value ? 1 : 0;
@@ -1782,6 +1850,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "fuse_tail3") *value = h->fuse_tail3;
     else if (k == "tail3_variant") *value = g_tail3_variant;
     else if (k == "tail3_bp") *value = g_tail3_bp;
+    else if (k == "fuse_cat_chain") *value = h->fuse_cat_chain;
     else if (k == "fuse_fp8_handover") *value = h->fuse_fp8_handover;
     else if (k == "fuse_stem_c1") *value = h->fuse_stem_c1;
     else if (k == "fuse_ds_cat") *value = h->fuse_ds_cat;
@@ -1944,6 +2013,22 @@ int r50_op_bneck_block2(const void* t1, int n, const void* w2, const float* b2, 
     const hipError_t e = launch_bneck_block2(t1, n, w2, b2, w3, b3, res, out, w1, b1, y1n, (hipStream_t)stream);
     if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
                                      std::string("r50_op_bneck_block2: ") + hipGetErrorString(e));
+    return R50_OK;
+}
+
+int r50_op_bneck_cat_chain(const void* t2, const void* x, int n, int ow, const void* wcat, const float* bcat, void* out, const void* w1,
+                           const float* b1, void* y1n, void* stream) {
+    // plain weight matrices in, packed per call into a buffer allocated and freed in the caller's stream order (as r50_op_bneck_tail does)
+    void* wp = nullptr;
+    if (!wcat || !w1) return fail(nullptr, R50_ERR_INVALID, "r50_op_bneck_cat_chain: null weights");
+    if (hipMallocAsync(&wp, kCatChainPackedBytes, (hipStream_t)stream) != hipSuccess || !wp)
+        return fail(nullptr, R50_ERR_HIP, "r50_op_bneck_cat_chain: hipMallocAsync");
+    hipError_t e = pack_catchain_weights(wcat, w1, wp, (hipStream_t)stream);
+    if (e == hipSuccess) e = launch_bneck_catchain(t2, x, n, ow, wp, bcat, out, b1, y1n, (hipStream_t)stream);
+    const hipError_t ef = hipFreeAsync(wp, (hipStream_t)stream);
+    if (e == hipSuccess) e = ef;
+    if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
+                                     std::string("r50_op_bneck_cat_chain: ") + hipGetErrorString(e));
     return R50_OK;
 }
 

@@ -206,6 +206,26 @@ def bneck_block2_bf16(t1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, w3: 
     return out, y1n
 
 
+def bneck_cat_chain_bf16(t2: torch.Tensor, x: torch.Tensor, wcat: torch.Tensor, bcat: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor):
+    """layer2.0's transition tail chained with layer2.1.conv1 in one launch (``r50_op_bneck_cat_chain``): t2 (N,28,28,128), block input x
+    (N,56,56,256) bf16 NHWC; wcat (512,384) = [W3 | Wd], w1 (128,512) bf16, K contiguous; bcat = b3 + bd, b1 fp32.
+    Returns (block output (N,28,28,512), next t1 (N,28,28,128))."""
+    for t, name in ((t2, "t2"), (x, "x"), (wcat, "wcat"), (w1, "w1")):
+        _need(t, torch.bfloat16, name)
+    _need(bcat, torch.float32, "bcat"); _need(b1, torch.float32, "b1")
+    n = t2.shape[0]
+    if tuple(t2.shape) != (n, 28, 28, 128) or tuple(x.shape) != (n, 56, 56, 256) or tuple(wcat.shape) != (512, 384) or tuple(w1.shape) != (128, 512) \
+            or bcat.numel() != 512 or b1.numel() != 128:
+        raise ValueError("bneck_cat_chain_bf16: inconsistent shapes")
+    out = torch.empty((n, 28, 28, 512), dtype=torch.bfloat16, device=t2.device)
+    y1n = torch.empty((n, 28, 28, 128), dtype=torch.bfloat16, device=t2.device)
+    with torch.cuda.device(t2.device):
+        rc = _lib.load_library().r50_op_bneck_cat_chain(t2.data_ptr(), x.data_ptr(), n, 28, wcat.data_ptr(), bcat.data_ptr(), out.data_ptr(),
+                                                        w1.data_ptr(), b1.data_ptr(), y1n.data_ptr(), _stream(t2))
+    _lib.check(rc, None, "r50_op_bneck_cat_chain")
+    return out, y1n
+
+
 def bneck_block1_bf16(t1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, identity: torch.Tensor,
                       w1: torch.Tensor, b1: torch.Tensor):
     """Layer1 bottleneck body in one launch (``r50_op_bneck_block1``): t1 (N,56,56,64), identity (N,56,56,256) bf16 NHWC; w2 (64,3,3,64),

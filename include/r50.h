@@ -207,6 +207,15 @@ int r50_op_bneck_tail(const void* y2_bf16, int64_t m, int cmid, const void* w3_b
 int r50_op_bneck_block2(const void* t1_bf16, int n, const void* w2_bf16, const float* b2, const void* w3_bf16, const float* b3,
                         const void* identity_bf16, void* out_bf16, const void* w1_bf16, const float* b1, void* y1n_bf16, void* stream);
 
+/* The TRANSITION tail of layer2.0 chained with layer2.1.conv1 in one launch: out = relu([W3 | Wd] . [t2 ; x at stride 2] + (b3 + bd)) -- conv3,
+ * the downsample conv, the add and the ReLU of torchvision's first Bottleneck of a stage (`out = relu(bn3(conv3(out)) + downsample(x))`,
+ * src/preprocess_resnet_features.py:296 through nn.Sequential) as one 1x1 conv over two K sources, as r50_op_conv1x1_cat computes it -- and
+ * y1n = relu(w1 . out + b1), the next block's conv1.  t2 (n,ow,ow,128), x (n,2ow,2ow,256), out (n,ow,ow,512), y1n (n,ow,ow,128) bf16 NHWC;
+ * wcat (512, 128 + 256) = [W3 | Wd], w1 (128,512) folded bf16, K contiguous; bcat = b3 + bd, b1 fp32.  ow = 28.  Bit for bit what
+ * r50_op_conv1x1_cat followed by a 1x1 r50_op_conv2d give. */
+int r50_op_bneck_cat_chain(const void* t2_bf16, const void* x_bf16, int n, int ow, const void* wcat_bf16, const float* bcat, void* out_bf16,
+                           const void* w1_bf16, const float* b1, void* y1n_bf16, void* stream);
+
 /* The same for layer1 (blocks .1 / .2, 56x56, 64 mid channels): t1 (n,56,56,64), identity / out (n,56,56,256), w2 (64,3,3,64), w3 (256,64),
  * w1 (c1,256) with c1 = 64 (the next layer1 block's conv1) or 128 (layer2.0.conv1), y1n (n,56,56,c1).  Bit for bit what the
  * resident-weights 3x3 launch followed by two r50_op_conv2d 1x1 launches give. */

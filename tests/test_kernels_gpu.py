@@ -379,6 +379,42 @@ def test_bneck_tail_layer3_batch256_equals_unfused(lib_built, variant, monkeypat
     assert torch.equal(out, out_u) and torch.equal(y1n, y1_u)
 
 
+@pytest.mark.parametrize("n", [1, 3, 37, 256], ids=lambda v: "n%d" % v)
+def test_bneck_cat_chain_equals_the_two_launches(lib_built, n):
+    """layer2.0's transition tail chained with layer2.1.conv1 (bneck_catchain_kernel): conv3 + downsample as one conv over K = [t2 | x at
+    stride 2] + ReLU, then the next 1x1 + ReLU out of LDS -- BIT FOR BIT the two-source igemm launch followed by the 1x1 igemm launch it
+    replaces (n = 1 / 3: fewer tiles than CUs, ragged tiles; 37: full tiles + a ragged one; 256: the benchmarked 1792 tiles, 7 per workgroup),
+    nothing stored past M; the small cases also against the oracle's emulation."""
+    from implementation_phd_lab_vision_amd import ops
+    from oracle.resnet50_oracle import conv_bias_act_emulated
+    g = torch.Generator().manual_seed(5100 + n)
+    t2 = _rand_bf16((n, 128, 28, 28), g)
+    x = _rand_bf16((n, 256, 56, 56), g)
+    w3 = _rand_bf16((512, 128, 1, 1), g, scale=(1.0 / 128) ** 0.5)
+    wd = _rand_bf16((512, 256, 1, 1), g, scale=(1.0 / 256) ** 0.5)
+    bcat = torch.randn(512, generator=g) * 0.1
+    w1 = _rand_bf16((128, 512, 1, 1), g, scale=(2.0 / 512) ** 0.5)
+    b1 = torch.randn(128, generator=g) * 0.1
+    d = _dev()
+    t2d = t2.permute(0, 2, 3, 1).contiguous().to(d)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(d)
+    wcat = torch.cat([w3.view(512, 128), wd.view(512, 256)], dim=1).contiguous().to(d)
+    w1d = w1.view(128, 512).contiguous().to(d)
+    bcd, b1d = bcat.to(d), b1.to(d)
+    out, y1n = ops.bneck_cat_chain_bf16(t2d, xd, wcat, bcd, w1d, b1d)
+    torch.cuda.synchronize()
+    out_u = ops.conv1x1_cat(t2d, xd, 2, wcat, bcd, relu=True)
+    y1_u = ops.conv2d_bf16(out_u, w1d.view(128, 1, 1, 512), b1d, relu=True)
+    assert torch.equal(out, out_u), "chained block output differs from the two-source igemm launch"
+    assert torch.equal(y1n, y1_u), "chained next-conv1 output differs from the igemm launch"
+    if n <= 3:
+        xs = x[:, :, ::2, ::2]
+        ref = conv_bias_act_emulated(torch.cat([t2, xs], dim=1).float(), torch.cat([w3, wd], dim=1).float(), bcat, 1, 0, True)
+        _check_bf16(out, ref, "bneck_cat_chain out")
+        y1_ref = conv_bias_act_emulated(out.float().cpu().permute(0, 3, 1, 2), w1.float(), b1, 1, 0, True)
+        _check_bf16(y1n, y1_ref, "bneck_cat_chain y1n")
+
+
 FP16_CASES = [CONV_CASES[i] for i in (1, 2, 3, 5, 6, 10, 12)]
 
 

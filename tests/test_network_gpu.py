@@ -518,3 +518,18 @@ def test_backbone_lanes_give_the_bits_of_one_backbone():
     finally:
         one.close()
         two.close()
+
+
+def test_layer2_0_chained_transition_tail_is_bit_identical(setup):
+    """layer2.0: conv3 + downsample + ReLU (one two-source conv) chained with layer2.1.conv1 in one launch (bneck_catchain_kernel, option
+    fuse_cat_chain, default on) -- same features bit for bit as the two igemm launches it replaces; the block output tap too."""
+    bb, x, *_ = setup
+    xd = x.to("cuda:0")
+    assert bb.get_option("fuse_cat_chain") == 1
+    fused = bb.features(xd).clone()
+    bb.set_option("fuse_cat_chain", 0)
+    try:
+        plain = bb.features(xd).clone()
+    finally:
+        bb.set_option("fuse_cat_chain", 1)
+    assert torch.equal(fused, plain)
