@@ -207,7 +207,7 @@ def main() -> None:
     ap.add_argument("--no-overlap-ds", action="store_true", help="A/B: downsample convs on the main stream")
     ap.add_argument("--no-cat-chain", action="store_true", help="A/B: layer2.0's conv3 + downsample launch and layer2.1.conv1 as two igemm launches")
     ap.add_argument("--no-block2", action="store_true", help="A/B: layer2.1-.3 as conv2 launch + fused tail instead of one launch per bottleneck body")
-    ap.add_argument("--block1", type=int, default=-1, help="A/B: option fuse_block1 (0 = layer1 as conv2 launch + fused tail, 1 = layer1.1 in one launch, 2 = layer1.2 too: the default)")
+    ap.add_argument("--block1", type=int, default=-1, help="A/B: option fuse_block1 (0 = layer1 as conv2 launch + fused tail, 1 = layer1.1 in one launch, 2 = layer1.2 too, 3 = layer1.0 too: the default)")
     ap.add_argument("--inplace", action="store_true", help="A/B: plain-identity blocks write their output over their input (same bits; measured: no gain)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="A/B: any library option (r50_set_option), e.g. --opt tail3_bp=112")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -4048,7 +4048,9 @@ struct Block1Args {
     const float* b2;      // (64)
     const __bf16* w3;     // (256, 64)
     const float* b3;      // (256)
-    const __bf16* res;    // (M, 256)  identity
+    const __bf16* res;    // (M, 256)  identity;  DS: (M, 64) the block INPUT, the identity is bf16(wd . input + bd) computed in the kernel
+    const __bf16* wd;     // DS: (256, 64) folded downsample weights
+    const float* bd;      // DS: (256)
     __bf16* out;          // (M, 256)  block output
     const __bf16* w1;     // (C1N, 256) next conv1
     const float* b1;      // (C1N)
@@ -4057,7 +4059,7 @@ struct Block1Args {
     int n_tiles;          // 14 N
 };
 
-template <int ET, int C1N>
+template <int ET, int C1N, bool DS = false>
 __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(C1N == 64 || C1N == 128, "next conv1: 256 -> 64 or 256 -> 128");
@@ -4069,8 +4071,13 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
     constexpr int NST = 3, WSTAGE = 64 * 128, WPASS = 2;
     constexpr int BIAS_OFF = RING_OFF + NST * WSTAGE;                     // b2 (64) | b3 (256) | b1 (C1N) floats
     constexpr int NB1 = C1N / 64;                                         // B stages per chunk
-    constexpr int NCONV = 9, LCH = 1 + NB1, SPT = NCONV + 4 * LCH;        // 17 / 21 stages per tile
-    static_assert(BIAS_OFF + 448 * 4 <= 163840, "LDS map");
+    // DS (layer1.0, round 3): the identity is the downsample conv of the block input -- one more 8-KB weight stage per chunk (Wd[64 c ..]) against the
+    // tile's 224 input rows, which take the place of the identity rows in RESB (fetched once per tile instead of once per chunk), into a second
+    // accumulator set that is rounded to 16 bits exactly as the separate downsample launch stores it and then added like an identity
+    constexpr int NA = DS ? 2 : 1;                                        // A stages per chunk
+    constexpr int NCONV = 9, LCH = NA + NB1, SPT = NCONV + 4 * LCH;       // 17 / 21 stages per tile (DS, C1N = 64: 21)
+    constexpr int BD_IDX = 64 + 256 + C1N;                                // bd (256) behind b1
+    static_assert(BIAS_OFF + (448 + 256) * 4 <= 163840, "LDS map");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -4083,6 +4090,7 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
         else v = a.b1[tid - 320];
         reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = v;
     }
+    if (DS && tid >= 512) reinterpret_cast<float*>(smem + BIAS_OFF)[BD_IDX + tid - 512] = a.bd[tid - 512];
 
     if (wave >= 8) {
         // =============================== loader waves ===============================================
@@ -4092,9 +4100,10 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
         const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w3), 0, 256u * 64u * 2u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w1), 0, (unsigned)C1N * 256u * 2u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.t1), 0, (unsigned)a.N * (3136u * 128u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.N * (3136u * 512u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.N * (3136u * (DS ? 128u : 512u)), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_wd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(DS ? a.wd : a.w3), 0, 256u * 64u * 2u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.N * (3136u * 512u), 0x00020000);
-        unsigned w2v[WPASS], w3v[WPASS], w1v[WPASS], x_voff[XPASS], rv[7];
+        unsigned w2v[WPASS], w3v[WPASS], w1v[WPASS], x_voff[XPASS], rv[7], rvx[7];
 #pragma unroll
         for (int i = 0; i < WPASS; ++i) {
             const int rho = i * 32 + srow;                               // LDS row of the stage (< 64)
@@ -4108,6 +4117,7 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
         for (int i = 0; i < 7; ++i) {             // rows of a 64-channel chunk of the identity / block output: row R = 32 i + srow of the tile
             const int R = 32 * i + srow;
             rv[i] = ((unsigned)R * 256u + (unsigned)((slot ^ (R & 7)) * 8)) * 2u;
+            rvx[i] = ((unsigned)R * 64u + (unsigned)((slot ^ (R & 7)) * 8)) * 2u;          // DS: the same rows of the 64-channel block input
         }
         auto decode_band = [&](int tile) {        // source offsets of the padded positions of `tile` (out of range = zero border)
             const int n = tile / 14, tr = tile - n * 14;
@@ -4126,11 +4136,11 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
                 if (i >= i0 && i < i1)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + XB_OFF + i * 4096 + lw * 1024), 16, x_voff[i], 0, 0, 0);
         };
-        auto issue_res = [&](unsigned tile_pix0, int c) {       // 7 DMAs per wave: identity rows of chunk c
-            const int sofs = __builtin_amdgcn_readfirstlane((int)(tile_pix0 * 512u) + c * 128);
+        auto issue_res = [&](unsigned tile_pix0, int c) {       // 7 DMAs per wave: identity rows of chunk c (DS: the tile's block-input rows)
+            const int sofs = __builtin_amdgcn_readfirstlane(DS ? (int)(tile_pix0 * 128u) : (int)(tile_pix0 * 512u) + c * 128);
 #pragma unroll
             for (int i = 0; i < 7; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(smem + RESB_OFF + i * 4096 + lw * 1024), 16, rv[i], sofs, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(smem + RESB_OFF + i * 4096 + lw * 1024), 16, DS ? rvx[i] : rv[i], sofs, 0, 0);
         };
         auto copy_out = [&](unsigned tile_pix0, int c) {        // 7 LDS reads + 7 stores per wave: out_c -> block output
             const int sofs = __builtin_amdgcn_readfirstlane((int)(tile_pix0 * 512u) + c * 128);
@@ -4151,13 +4161,13 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (LDS_AS void*)(sbase + i * 4096), 16, w2v[i], sofs, 0, 0);
             } else {
                 const int q = p - NCONV, c = q / LCH, r = q - c * LCH;
-                if (r == 0) {
+                if (r < NA) {                     // W3[64 c ..], then (DS) Wd[64 c ..]: same (256, 64) layout
                     const int sofs = __builtin_amdgcn_readfirstlane(c * 64 * 64 * 2);
 #pragma unroll
                     for (int i = 0; i < WPASS; ++i)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (LDS_AS void*)(sbase + i * 4096), 16, w3v[i], sofs, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(r == 0 ? rs_w3 : rs_wd, (LDS_AS void*)(sbase + i * 4096), 16, w3v[i], sofs, 0, 0);
                 } else {
-                    const int sofs = __builtin_amdgcn_readfirstlane(((r - 1) * 64 * 256 + c * 64) * 2);
+                    const int sofs = __builtin_amdgcn_readfirstlane(((r - NA) * 64 * 256 + c * 64) * 2);
 #pragma unroll
                     for (int i = 0; i < WPASS; ++i)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (LDS_AS void*)(sbase + i * 4096), 16, w1v[i], sofs, 0, 0);
@@ -4180,13 +4190,13 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
             for (int p = 0; p < SPT; ++p) {
                 const int q = p - NCONV, c = q >= 0 ? q / LCH : -1, r = q >= 0 ? q - c * LCH : -1;
                 // the consumers' extra barriers: T2 complete (in front of the first A stage), OUTC(c) complete (in front of the first B stage)
-                if (p == NCONV || r == 1) __builtin_amdgcn_s_barrier();
+                if (p == NCONV || r == NA) __builtin_amdgcn_s_barrier();
                 int younger = carry;
                 carry = 0;
                 // identity rows: chunk 0 two stages before the first A stage (RESB is free since the previous tile's last E), chunk c + 1
                 // right behind E(c) -- they have to be in LDS one barrier later (A(c + 1)), or two (C1N = 128)
                 if (p == NCONV - 2) { issue_res(tile_pix0, 0); younger += 7; }
-                if (r == 1 && c < 3) { issue_res(tile_pix0, c + 1); younger += 7; }
+                if (!DS && r == 1 && c < 3) { issue_res(tile_pix0, c + 1); younger += 7; }
                 // the next tile's band: its buffer is dead once conv2 is done (behind the T2 barrier); spread over the tail's first positions
                 if (has_next && p >= NCONV && p < NCONV + 4) {
                     if (p == NCONV) decode_band(tile + grid);
@@ -4198,7 +4208,7 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
                 if (st) { stage_issue(p + 2 < SPT ? p + 2 : p + 2 - SPT); younger += WPASS; }
                 // out_c(c), complete behind the OUTC barrier, is intact until E(c + 1): copied out one position later (C1N = 64: the A(c + 1)
                 // position; C1N = 128: the second B position), chunk 3 at the tile's last position
-                const bool cpos = (C1N == 64) ? ((r == 0 && c >= 1) || p == SPT - 1) : (r == 2);
+                const bool cpos = (C1N == 64) ? ((r == 0 && c >= 1) || p == SPT - 1) : (r == NA + 1);
                 if (cpos) {
                     copy_out(tile_pix0, (C1N == 64 && p != SPT - 1) ? c - 1 : c);
                     younger += 7;
@@ -4223,7 +4233,7 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
 
         auto run = [&](auto nq_c) {
             constexpr int NQ = decltype(nq_c)::value;
-            f32x4 acc[2][NQ], accB[NB1][2][NQ];
+            f32x4 acc[2][NQ], accB[NB1][2][NQ], accD[2][DS ? NQ : 1];
             int cbuf = 0;
             auto gemm64 = [&](const char* wb, auto xaddr, auto& ac) {
                 constexpr int NS = 2 * NQ, PD = 3;
@@ -4302,12 +4312,21 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
                     // ---- A(c): W3[64 c ..] . t2
                     gemm64(smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) { return smem + T2_OFF + ((pb0 + 2048 * (t % NQ)) ^ (t >= NQ ? 64 : 0)); }, acc);
                     stage_done();
+                    if constexpr (DS) {           // ---- the identity's chunk: Wd[64 c ..] . block input (the tile's rows, in RESB) from bias bd
+                        set_bias(accD, BD_IDX + 64 * c);
+                        gemm64(smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) { return smem + RESB_OFF + ((pb0 + 2048 * (t % NQ)) ^ (t >= NQ ? 64 : 0)); }, accD);
+                        stage_done();
+                    }
                     // ---- E(c): + identity (RESB, landed with this stage's barrier), ReLU, 16 bit -> OUTC: the block output's chunk (the loaders
                     //      copy it out) and the next conv1's K-slice
                     {
                         u32x4 rr[NQ];
 #pragma unroll
-                        for (int j = 0; j < NQ; ++j) rr[j] = *reinterpret_cast<const u32x4*>(smem + RESB_OFF + ((pb0 + 2048 * j) ^ cf_x));
+                        for (int j = 0; j < NQ; ++j) {
+                            if constexpr (DS) rr[j] = (u32x4){pack2_e<ET>(accD[0][j][0], accD[0][j][1]), pack2_e<ET>(accD[0][j][2], accD[0][j][3]),
+                                                              pack2_e<ET>(accD[1][j][0], accD[1][j][1]), pack2_e<ET>(accD[1][j][2], accD[1][j][3])};
+                            else rr[j] = *reinterpret_cast<const u32x4*>(smem + RESB_OFF + ((pb0 + 2048 * j) ^ cf_x));
+                        }
 #pragma unroll
                         for (int j = 0; j < NQ; ++j) {
                             f32x4 lo = acc[0][j], hi = acc[1][j];

@@ -71,7 +71,7 @@ struct r50_handle {
     __bf16* catchain_wp = nullptr;      // layer2.0: [W3 | Wd] and layer2.1.conv1 in bneck_catchain_kernel's fragment-ordered stream
     int fuse_cat_chain = 1;             // layer2.0: conv3 + downsample + ReLU chained with layer2.1.conv1 in one launch (bneck_catchain_kernel)
     __bf16* tail3_wp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per layer3 block b: [W3(b) | W1(b+1)] in the kernel's fragment order
-    int fuse_block1 = 2;                // 1: layer1.1, 2 (default since round 3: with the loaders' position loop unrolled the c1 = 128 form takes 248 us against
+    int fuse_block1 = 3;                // 1: layer1.1, 2 (default since round 3: with the loaders' position loop unrolled the c1 = 128 form takes 248 us against
                                         // 276 for conv2 + fused tail): also layer1.2 -- the bottleneck body in one launch (bneck_block1_kernel)
     int fuse_block2 = 1;                // layer2.1-.3: the whole bottleneck body (conv2 + conv3 + identity + ReLU [+ next conv1]) in one launch
     int inplace_out = 0;                // plain-identity blocks write their output over their input (same bits, fewer DRAM page switches)
@@ -903,9 +903,11 @@ hipError_t launch_bneck_block2(const void* t1, int n, const void* w2, const floa
 
 // layer1.1 / .2 bottleneck body in one launch (kernels.h: bneck_block1_kernel): conv2 + conv3 + identity + ReLU + the next conv1 (c1 = 64 or 128)
 hipError_t launch_bneck_block1(const void* t1, int n, const void* w2, const float* b2, const void* w3, const float* b3, const void* res,
-                               void* out, const void* w1, int c1, const float* b1, void* y1n, hipStream_t s, int et = 0) {
+                               void* out, const void* w1, int c1, const float* b1, void* y1n, hipStream_t s, int et = 0,
+                               const void* wd = nullptr, const float* bd = nullptr) {
     if (!t1 || !w2 || !b2 || !w3 || !b3 || !res || !out || !w1 || !b1 || !y1n || n <= 0 || (long long)n * 3136 * 512 >= (1ll << 31)) return hipErrorInvalidValue;
     if (c1 != 64 && c1 != 128) return hipErrorInvalidValue;
+    if ((wd == nullptr) != (bd == nullptr) || (wd && c1 != 64)) return hipErrorInvalidValue;       // downsample form: layer1.0 (next conv1 256 -> 64)
     if (g_num_cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -915,10 +917,12 @@ hipError_t launch_bneck_block1(const void* t1, int n, const void* w2, const floa
     Block1Args a;
     a.t1 = (const __bf16*)t1; a.w2 = (const __bf16*)w2; a.b2 = b2; a.w3 = (const __bf16*)w3; a.b3 = b3; a.res = (const __bf16*)res;
     a.out = (__bf16*)out; a.w1 = (const __bf16*)w1; a.b1 = b1; a.y1n = (__bf16*)y1n; a.N = n; a.n_tiles = 14 * n;
+    a.wd = (const __bf16*)wd; a.bd = bd;
     const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
-    constexpr size_t lds = 11 * 32 * 128 + 3 * 224 * 128 + 3 * 8192 + 448 * 4;       // 157,440 (kernels.h: LDS map)
+    constexpr size_t lds = 11 * 32 * 128 + 3 * 224 * 128 + 3 * 8192 + (448 + 256) * 4;       // 158,464 (kernels.h: LDS map; bd behind b1)
     void (*kern)(const Block1Args);
-    if (c1 == 64) kern = et == 1 ? bneck_block1_kernel<1, 64> : bneck_block1_kernel<0, 64>;
+    if (wd) kern = et == 1 ? bneck_block1_kernel<1, 64, true> : bneck_block1_kernel<0, 64, true>;
+    else if (c1 == 64) kern = et == 1 ? bneck_block1_kernel<1, 64> : bneck_block1_kernel<0, 64>;
     else kern = et == 1 ? bneck_block1_kernel<1, 128> : bneck_block1_kernel<0, 128>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1333,6 +1337,31 @@ after_pool:
                                 (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16 || (h->precision == R50_PREC_FP8 && nx->cout == 64)) &&
                                 hh == 56 && ww == 56 && c1.cout == 64 && c2.ks == 3 && c2.stride == 1 && c2.pad == 1 && c2.cin == 64 && c2.cout == 64 &&
                                 c3.ks == 1 && c3.cin == 64 && c3.cout == 256;
+            // layer1.0 (option "fuse_block1" = 3, the default since round 3's second session): the same body kernel with the downsample conv
+            // of the block input as the identity (bneck_block1_kernel<.., DS>): conv3x3_c64 + fused tail (t2 written and read back) become one launch
+            const bool block1_ds = h->fuse_block1 >= 3 && h->fuse_tail && !split && !tap && si == 0 && b == 0 && h->tile_override == 0 && cdp && nx &&
+                                   (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16 || h->precision == R50_PREC_FP8) && hh == 56 && ww == 56 &&
+                                   c1.cout == 64 && c2.ks == 3 && c2.stride == 1 && c2.pad == 1 && c2.cin == 64 && c2.cout == 64 && c3.ks == 1 && c3.cin == 64 &&
+                                   c3.cout == 256 && cdp->ks == 1 && cdp->stride == 1 && cdp->cin == 64 && cdp->cout == 256 && nx->ks == 1 && nx->stride == 1 &&
+                                   nx->cin == 256 && nx->cout == 64 && !nx_is_fp8;
+            if (block1_ds) {
+                if (!have_t1) {
+                    rc = run_conv(h, c1, buf[cur], n, hh, ww, nullptr, buf[fr[0]], 1, s, &h1, &w1);
+                    if (rc) return rc;
+                }
+                const double m = (double)n * 3136.0;
+                EvRec rb{};
+                prof_begin(h, s, rb, PC_BLOCK2, 2.0 * m * (64.0 * 576 + 2 * 256.0 * 64 + 64.0 * 256),
+                           2.0 * (m * (64.0 + 64 + 256 + 64) + 64.0 * 576 + 2 * 256.0 * 64 + 64.0 * 256), (int)(&c2 - &h->convs[0]));
+                e = launch_bneck_block1(buf[fr[0]], n, c2.w, c2.bias, c3.w, c3.bias, buf[cur], buf[fr[3]], nx->w, 64, nx->bias, buf[fr[1]], s, et,
+                                        cdp->w, cdp->bias);
+                prof_end(h, s, rb);
+                if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_block1 (downsample) launch (" + c2.conv_key + "): " + hipGetErrorString(e));
+                pre_t1 = fr[1];
+                cur = fr[3];
+                li += 4;
+                continue;
+            }
             if (block1) {
                 if (!have_t1) {
                     rc = run_conv(h, c1, buf[cur], n, hh, ww, nullptr, buf[fr[0]], 1, s, &h1, &w1);
@@ -1826,7 +1855,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "streams") { if (value < 1 || value > 4) return fail(h, R50_ERR_INVALID, "streams must be in [1,4]"); h->n_streams = (int)value; }
     else if (k == "inplace_out") h->inplace_out = value ? 1 : 0;
     else if (k == "fuse_block2") h->fuse_block2 = value ? 1 : 0;
-    else if (k == "fuse_block1") { if (value < 0 || value > 2) return fail(h, R50_ERR_INVALID, "fuse_block1 must be 0, 1 or 2"); h->fuse_block1 = (int)value; }
+    else if (k == "fuse_block1") { if (value < 0 || value > 3) return fail(h, R50_ERR_INVALID, "fuse_block1 must be 0 .. 3"); h->fuse_block1 = (int)value; }
     else if (k == "xres_variant") g_xres_variant = (int)value;        // process-wide A/B knob
     else if (k == "use_s2") g_use_s2 = (int)value;                     // process-wide A/B knob: 0 = generic tiles for the stride-2 3x3 shapes
     else if (k == "cu_cap") { if (value < 0 || value > 4096) return fail(h, R50_ERR_INVALID, "cu_cap must be in [0,4096]"); g_cu_cap = (int)value; g_num_cus = 0; }
@@ -2013,6 +2042,15 @@ int r50_op_bneck_block2(const void* t1, int n, const void* w2, const float* b2, 
     const hipError_t e = launch_bneck_block2(t1, n, w2, b2, w3, b3, res, out, w1, b1, y1n, (hipStream_t)stream);
     if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
                                      std::string("r50_op_bneck_block2: ") + hipGetErrorString(e));
+    return R50_OK;
+}
+
+int r50_op_bneck_block1_ds(const void* t1, int n, const void* w2, const float* b2, const void* w3, const float* b3, const void* x, const void* wd,
+                           const float* bd, void* out, const void* w1, const float* b1, void* y1n, void* stream) {
+    if (!wd || !bd) return fail(nullptr, R50_ERR_INVALID, "r50_op_bneck_block1_ds: null downsample weights");
+    const hipError_t e = launch_bneck_block1(t1, n, w2, b2, w3, b3, x, out, w1, 64, b1, y1n, (hipStream_t)stream, 0, wd, bd);
+    if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
+                                     std::string("r50_op_bneck_block1_ds: ") + hipGetErrorString(e));
     return R50_OK;
 }
 

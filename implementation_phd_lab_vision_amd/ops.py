@@ -206,6 +206,28 @@ def bneck_block2_bf16(t1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, w3: 
     return out, y1n
 
 
+def bneck_block1_ds_bf16(t1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, x: torch.Tensor,
+                         wd: torch.Tensor, bd: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor):
+    """layer1.0's bottleneck body in one launch (``r50_op_bneck_block1_ds``): t1 (N,56,56,64), block input x (N,56,56,64) bf16 NHWC; w2 (64,3,3,64),
+    w3 (256,64), wd (256,64), w1 (64,256) bf16; biases fp32.  Returns (block output (N,56,56,256), next t1 (N,56,56,64))."""
+    for t, name in ((t1, "t1"), (w2, "w2"), (w3, "w3"), (x, "x"), (wd, "wd"), (w1, "w1")):
+        _need(t, torch.bfloat16, name)
+    for t, name in ((b2, "b2"), (b3, "b3"), (bd, "bd"), (b1, "b1")):
+        _need(t, torch.float32, name)
+    n = t1.shape[0]
+    if tuple(t1.shape) != (n, 56, 56, 64) or tuple(x.shape) != (n, 56, 56, 64) or tuple(w2.shape) != (64, 3, 3, 64) or tuple(w3.shape) != (256, 64) \
+            or tuple(wd.shape) != (256, 64) or tuple(w1.shape) != (64, 256) or b2.numel() != 64 or b3.numel() != 256 or bd.numel() != 256 or b1.numel() != 64:
+        raise ValueError("bneck_block1_ds_bf16: inconsistent shapes")
+    out = torch.empty((n, 56, 56, 256), dtype=torch.bfloat16, device=t1.device)
+    y1n = torch.empty((n, 56, 56, 64), dtype=torch.bfloat16, device=t1.device)
+    with torch.cuda.device(t1.device):
+        rc = _lib.load_library().r50_op_bneck_block1_ds(t1.data_ptr(), n, w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), x.data_ptr(),
+                                                        wd.data_ptr(), bd.data_ptr(), out.data_ptr(), w1.data_ptr(), b1.data_ptr(), y1n.data_ptr(),
+                                                        _stream(t1))
+    _lib.check(rc, None, "r50_op_bneck_block1_ds")
+    return out, y1n
+
+
 def bneck_cat_chain_bf16(t2: torch.Tensor, x: torch.Tensor, wcat: torch.Tensor, bcat: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor):
     """layer2.0's transition tail chained with layer2.1.conv1 in one launch (``r50_op_bneck_cat_chain``): t2 (N,28,28,128), block input x
     (N,56,56,256) bf16 NHWC; wcat (512,384) = [W3 | Wd], w1 (128,512) bf16, K contiguous; bcat = b3 + bd, b1 fp32.

@@ -207,6 +207,14 @@ int r50_op_bneck_tail(const void* y2_bf16, int64_t m, int cmid, const void* w3_b
 int r50_op_bneck_block2(const void* t1_bf16, int n, const void* w2_bf16, const float* b2, const void* w3_bf16, const float* b3,
                         const void* identity_bf16, void* out_bf16, const void* w1_bf16, const float* b1, void* y1n_bf16, void* stream);
 
+/* layer1.0, the stage's first bottleneck, from its second conv on in one launch: as r50_op_bneck_block1 with c1 = 64, but the identity is the
+ * DOWNSAMPLE conv of the block input computed in the kernel -- identity = bf16(wd . x + bd), rounded exactly as a separate 1x1 launch stores
+ * it (torchvision `Bottleneck.forward`: `identity = self.downsample(x)`).  x (n,56,56,64) the block input, wd (256,64), bd (256).  Bit for bit
+ * what the resident-weights 3x3 launch followed by r50_op_bneck_tail (cmid 64, wd / bd given) give. */
+int r50_op_bneck_block1_ds(const void* t1_bf16, int n, const void* w2_bf16, const float* b2, const void* w3_bf16, const float* b3,
+                           const void* x_bf16, const void* wd_bf16, const float* bd, void* out_bf16, const void* w1_bf16, const float* b1,
+                           void* y1n_bf16, void* stream);
+
 /* The TRANSITION tail of layer2.0 chained with layer2.1.conv1 in one launch: out = relu([W3 | Wd] . [t2 ; x at stride 2] + (b3 + bd)) -- conv3,
  * the downsample conv, the add and the ReLU of torchvision's first Bottleneck of a stage (`out = relu(bn3(conv3(out)) + downsample(x))`,
  * src/preprocess_resnet_features.py:296 through nn.Sequential) as one 1x1 conv over two K sources, as r50_op_conv1x1_cat computes it -- and

@@ -231,6 +231,34 @@ def test_bneck_block1_equals_unfused(lib_built, n, c1):
     assert torch.equal(y1n, y1_ref), f"next conv1 differs: max |diff| {float((y1n.float() - y1_ref.float()).abs().max())}"
 
 
+@pytest.mark.parametrize("n", [1, 3, 20])
+def test_bneck_block1_downsample_equals_unfused(lib_built, n):
+    """layer1.0's body in one launch (bneck_block1_kernel<.., DS>): the identity is the downsample conv of the block input, computed in the
+    kernel and rounded to bf16 as the separate launch stores it.  Block output and next t1 are the same bits as the resident-weights 3x3 launch,
+    the 1x1 downsample launch, the 1x1 conv3 launch with that identity, and the next 1x1 launch."""
+    from implementation_phd_lab_vision_amd import ops
+    g = torch.Generator().manual_seed(5300 + n)
+    d = _dev()
+    t1 = _rand_bf16((n, 56, 56, 64), g).clamp_(min=0).to(d)
+    x = _rand_bf16((n, 56, 56, 64), g).clamp_(min=0).to(d)
+    w2 = _rand_bf16((64, 3, 3, 64), g, scale=(2.0 / 576) ** 0.5).to(d)
+    w3 = _rand_bf16((256, 1, 1, 64), g, scale=(2.0 / 64) ** 0.5).to(d)
+    wd = _rand_bf16((256, 1, 1, 64), g, scale=(1.0 / 64) ** 0.5).to(d)
+    w1 = _rand_bf16((64, 1, 1, 256), g, scale=(2.0 / 256) ** 0.5).to(d)
+    b2 = (torch.randn(64, generator=g) * 0.1).to(d)
+    b3 = (torch.randn(256, generator=g) * 0.1).to(d)
+    bd = (torch.randn(256, generator=g) * 0.1).to(d)
+    b1 = (torch.randn(64, generator=g) * 0.1).to(d)
+    t2 = ops.conv2d_bf16(t1, w2, b2, stride=1, pad=1, relu=True, tile=ops.TILE_C64)
+    idn = ops.conv2d_bf16(x, wd, bd, stride=1, pad=0, relu=False)
+    out_ref = ops.conv2d_bf16(t2, w3, b3, stride=1, pad=0, relu=True, residual=idn)
+    y1_ref = ops.conv2d_bf16(out_ref, w1, b1, stride=1, pad=0, relu=True)
+    out, y1n = ops.bneck_block1_ds_bf16(t1, w2, b2, w3.view(256, 64), b3, x, wd.view(256, 64), bd, w1.view(64, 256), b1)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_ref), f"block output differs: max |diff| {float((out.float() - out_ref.float()).abs().max())}"
+    assert torch.equal(y1n, y1_ref), f"next conv1 differs: max |diff| {float((y1n.float() - y1_ref.float()).abs().max())}"
+
+
 @pytest.mark.parametrize("ds", [False, True], ids=["identity", "downsample"])
 @pytest.mark.parametrize("shape,c1", [((2, 7, 9), 64), ((1, 56, 56), 128), ((3, 5, 16), 64), ((5, 56, 56), 64)],
                          ids=lambda v: str(v).replace(" ", ""))

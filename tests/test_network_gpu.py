@@ -231,7 +231,8 @@ def test_default_fusions_give_the_bits_of_plain_launches(lib_built, precision):
     x = synthetic_frames(5, seed=77).to("cuda:0")
     bb = ResNet50Backbone(seed=0, max_batch=5, precision=precision).to("cuda:0").eval()
     try:
-        assert bb.get_option("fuse_block1") == 2 and bb.get_option("fuse_block2") == 1      # round 3: layer1.2 is one launch by default too
+        assert bb.get_option("fuse_block1") == 3 and bb.get_option("fuse_block2") == 1      # round 3: layer1.2 and layer1.0 are one launch each by default too
+        assert bb.get_option("fuse_cat_chain") == 1
         f_default = bb.features(x).clone()
         bb.set_option("fuse_block1", 1)
         f_b12 = bb.features(x).clone()                                                   # the round-2 default (layer1.2 as conv2 + fused tail)
@@ -533,3 +534,18 @@ def test_layer2_0_chained_transition_tail_is_bit_identical(setup):
     finally:
         bb.set_option("fuse_cat_chain", 1)
     assert torch.equal(fused, plain)
+
+
+def test_layer1_0_body_in_one_launch_is_bit_identical(setup):
+    """fuse_block1 = 3 (default): layer1.0 from its conv2 on is one launch of the bottleneck-body kernel with the downsample conv as the identity;
+    same features bit for bit as with conv3x3_c64 + the fused downsample tail (fuse_block1 = 2) and as layer by layer (0)."""
+    bb, x, *_ = setup
+    xd = x.to("cuda:0")
+    assert bb.get_option("fuse_block1") == 3
+    ref = bb.features(xd).clone()
+    try:
+        for v in (2, 0):
+            bb.set_option("fuse_block1", v)
+            assert torch.equal(bb.features(xd), ref), v
+    finally:
+        bb.set_option("fuse_block1", 3)
