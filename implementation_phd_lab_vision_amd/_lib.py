@@ -69,6 +69,7 @@ _SIGNATURES = {
     "r50_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
     "r50_destroy": (None, [C.c_void_p]),
     "r50_load_weights": (C.c_int, [C.c_void_p, C.POINTER(TensorDesc), C.c_int]),
+    "r50_share_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
     "r50_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "r50_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "r50_forward_layer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int64,

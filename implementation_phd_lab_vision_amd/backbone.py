@@ -67,7 +67,9 @@ class ResNet50Backbone:
         self.training = False
 
     # ---- nn.Module-like surface -------------------------------------------------------------
-    def to(self, device) -> "ResNet50Backbone":
+    def to(self, device, share_from: Optional["ResNet50Backbone"] = None) -> "ResNet50Backbone":
+        """``share_from``: another backbone of the same precision already on ``device`` -- this one then reads ITS folded / packed weight buffers
+        (``r50_share_weights``) instead of loading a copy of its own (bf16 / fp16; ``BackboneLanes`` uses it for the lanes behind the first)."""
         device = torch.device(device)
         if device.type != "cuda":
             raise _lib.R50Error(f"ResNet50Backbone runs on an MI355X only (got device '{device}'); "
@@ -82,6 +84,13 @@ class ResNet50Backbone:
         _lib.check(lib.r50_create(C.byref(h), index, self._precision, self._max_batch), None, "r50_create")
         self._handle = h.value
         self._device = device
+        if share_from is not None:
+            if share_from._handle is None or share_from._device != device or share_from._precision != self._precision:
+                raise ValueError("share_from must be a backbone of the same precision on the same device")
+            _lib.check(lib.r50_share_weights(self._handle, share_from._handle), self._handle, "r50_share_weights")
+            if self._micro_batch:
+                self.set_option("micro_batch", self._micro_batch)
+            return self
         named = list(iter_named_tensors(self._sd))
         descs = (_lib.TensorDesc * len(named))()
         keep = []
@@ -295,7 +304,8 @@ class BackboneLanes:
     before the tail has drained.  Batches are independent (the reference's call site runs them one after the other,
     src/preprocess_resnet_features.py:287-297), so with two batches in flight the workgroups of one batch's next launch fill the
     CUs the other batch's tail leaves idle: +5 % frames/s at batch 256 with the same bits (scripts/dual_stream_probe.py).
-    Each lane owns its activation buffers (and, today, its own copy of the 47 MB of weights).
+    Each lane owns its activation buffers; the folded / packed weights exist once (``r50_share_weights``; the fp8 and the multi-term modes keep
+    a copy per lane).
 
     ``submit`` enqueues a batch on the next lane and returns at once; the caller orders later work behind ``ticket.event``.
     ``features`` / ``__call__`` keep the one-batch surface of ``ResNet50Backbone`` (current stream waits for the result)."""
@@ -315,8 +325,13 @@ class BackboneLanes:
 
     # ---- nn.Module-like surface -------------------------------------------------------------
     def to(self, device) -> "BackboneLanes":
-        for bb in self._bbs:
-            bb.to(device)
+        self._bbs[0].to(device)
+        import os
+        share = self._bbs[0] if self._bbs[0]._precision in (PREC_BF16, PREC_FP16) else None      # one copy of the weights for all lanes
+        if os.environ.get("R50_LANES_SHARE") == "0":                                              # A/B knob: a copy per lane
+            share = None
+        for bb in self._bbs[1:]:
+            bb.to(device, share_from=share)
         self._device = self._bbs[0]._device
         if len(self._streams) != len(self._bbs):
             self._streams = [torch.cuda.Stream(self._device) for _ in self._bbs]

@@ -79,6 +79,11 @@ struct r50_handle {
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool loaded = false;
+    // r50_share_weights: this handle reads the weight buffers of `owner` (convs[].w / bias, cat_w / cat_bias, tail3_wp, catchain_wp, stem_w) and
+    // frees none of them; the owner counts its sharers and, if destroyed first, stays alive (weights only) until the last sharer is gone
+    r50_handle* owner = nullptr;
+    int sharers = 0;
+    bool zombie = false;
     std::string err;
     std::vector<ConvLayer> convs;       // execution order, convs[0] = stem
     char* stem_w = nullptr;             // packed stem weights (device)
@@ -1485,21 +1490,27 @@ after_pool:
     return R50_OK;
 }
 
-void free_all(r50_handle* h) {
+void free_weights(r50_handle* h) {        // the buffers a sharer reads through its owner
+    const bool own = (h->owner == nullptr);
     for (auto& L : h->convs) {
-        if (L.w) (void)hipFree(L.w);
-        if (L.bias) (void)hipFree(L.bias);
+        if (own && L.w) (void)hipFree(L.w);
+        if (own && L.bias) (void)hipFree(L.bias);
         if (L.bias_scaled) (void)hipFree(L.bias_scaled);
         L.w = nullptr; L.bias = nullptr; L.bias_scaled = nullptr;
     }
-    for (auto& p : h->tail3_wp) { if (p) (void)hipFree(p); p = nullptr; }
-    if (h->catchain_wp) { (void)hipFree(h->catchain_wp); h->catchain_wp = nullptr; }
+    for (auto& p : h->tail3_wp) { if (own && p) (void)hipFree(p); p = nullptr; }
+    if (own && h->catchain_wp) (void)hipFree(h->catchain_wp);
+    h->catchain_wp = nullptr;
     for (int i = 0; i < 4; ++i) {
-        if (h->cat_w[i]) (void)hipFree(h->cat_w[i]);
-        if (h->cat_bias[i]) (void)hipFree(h->cat_bias[i]);
+        if (own && h->cat_w[i]) (void)hipFree(h->cat_w[i]);
+        if (own && h->cat_bias[i]) (void)hipFree(h->cat_bias[i]);
         h->cat_w[i] = nullptr; h->cat_bias[i] = nullptr;
     }
-    if (h->stem_w) (void)hipFree(h->stem_w);
+    if (own && h->stem_w) (void)hipFree(h->stem_w);
+    h->stem_w = nullptr;
+}
+void free_all(r50_handle* h, bool keep_weights = false) {
+    if (!keep_weights) free_weights(h);
     if (h->stem_xp) (void)hipFree(h->stem_xp);
     if (h->u8_table) (void)hipFree(h->u8_table);
     for (auto& b : h->buf) { if (b) (void)hipFree(b); b = nullptr; }
@@ -1626,8 +1637,44 @@ void r50_destroy(r50_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    if (h->sharers > 0) {                 // other handles still read this one's weights: everything else goes now, the weights with the last sharer
+        free_all(h, /*keep_weights=*/true);
+        h->zombie = true;
+        return;
+    }
+    r50_handle* owner = h->owner;
     free_all(h);
     delete h;
+    if (owner && --owner->sharers == 0 && owner->zombie) {
+        free_weights(owner);
+        delete owner;
+    }
+}
+
+int r50_share_weights(r50_handle* h, r50_handle* from) {
+    if (!h || !from) return fail(h, R50_ERR_INVALID, "r50_share_weights: null handle");
+    if (h == from || h->owner || h->loaded) return fail(h, R50_ERR_STATE, "r50_share_weights: the handle already has weights");
+    if (!from->loaded || from->zombie) return fail(h, R50_ERR_STATE, "r50_share_weights: the source handle has no weights loaded");
+    if (from->owner) from = from->owner;
+    if (h->device != from->device || h->precision != from->precision)
+        return fail(h, R50_ERR_INVALID, "r50_share_weights: device and precision of the two handles must be the same");
+    if (h->precision != R50_PREC_BF16 && h->precision != R50_PREC_FP16)
+        return fail(h, R50_ERR_INVALID, "r50_share_weights: bf16 / fp16 handles only (the fp8 mode rewrites weight buffers per handle when its scales are set)");
+    (void)hipSetDevice(h->device);
+    if (h->stem_w) (void)hipFree(h->stem_w);                  // allocated by r50_create
+    h->stem_w = from->stem_w;
+    for (size_t i = 0; i < h->convs.size(); ++i) {
+        ConvLayer& L = h->convs[i];
+        const ConvLayer& S = from->convs[i];
+        L.w = S.w; L.bias = S.bias; L.wscale = S.wscale; L.bias_host = S.bias_host; L.w_host = S.w_host;
+    }
+    for (int i = 0; i < 4; ++i) { h->cat_w[i] = from->cat_w[i]; h->cat_bias[i] = from->cat_bias[i]; h->cat_acc_scale[i] = from->cat_acc_scale[i]; }
+    for (int b = 0; b < 8; ++b) h->tail3_wp[b] = from->tail3_wp[b];
+    h->catchain_wp = from->catchain_wp;
+    h->owner = from;
+    ++from->sharers;
+    h->loaded = true;
+    return R50_OK;
 }
 
 int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensors) {

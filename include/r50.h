@@ -75,6 +75,11 @@ int r50_create(r50_handle** out, int device_id, int precision, int max_batch);
  * The caller keeps ownership of the host buffers. */
 int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensors);
 
+/* Instead of r50_load_weights: `h` (fresh from r50_create, same device and precision as `from`, bf16 or fp16) reads the folded / packed weight buffers
+ * of `from` -- a second backbone copy for a second batch in flight (backbone.BackboneLanes) without a second copy of the 47 MB of weights.  `h` keeps
+ * its own activation workspace, streams, options and profile.  Either handle may be destroyed first: the buffers go with the last one. */
+int r50_share_weights(r50_handle* h, r50_handle* from);
+
 /* Replaces: backbone(x).flatten(1) (:242,296).  Asynchronous on `stream` (a hipStream_t; NULL =
  * default stream).  x_nchw_f32_dev: (n,3,224,224) fp32 on the device; out_f32_dev: (n,2048).
  * n may exceed max_batch: the call then loops over chunks of max_batch frames. */

@@ -516,6 +516,14 @@ def test_backbone_lanes_give_the_bits_of_one_backbone():
         two.set_option("tail3_variant", 0)
         assert two.lane0.get_option("tail3_variant") == 0
         two.set_option("tail3_variant", 1)
+        # the lanes read ONE copy of the weights (r50_share_weights): lane 1 survives lane 0's handle, and a third backbone can join
+        w0, _ = two._bbs[0].packed_params("layer3.1.conv2")
+        w1, _ = two._bbs[1].packed_params("layer3.1.conv2")
+        assert torch.equal(w0, w1)
+        two._bbs[0].close()
+        assert torch.equal(two._bbs[1].features(xs[1]), refs[1])
+        with pytest.raises(Exception):
+            ResNet50Backbone(state_dict=sd, max_batch=8, precision="fp16").to(dev, share_from=two._bbs[1])      # other precision
     finally:
         one.close()
         two.close()
