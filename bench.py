@@ -132,23 +132,40 @@ def timed_steps(step, fence, steps: int, warmup: int, preheat_s: float, frames_p
     return time.perf_counter() - t0, pre_rate
 
 
-def secondary_mode(precision: str, batch: int, steps: int, warmup: int, preheat_s: float, dev, sd) -> dict:
+def secondary_mode(precision: str, batch: int, steps: int, warmup: int, preheat_s: float, dev, sd, n_lanes: int = 1) -> dict:
     """A secondary, clearly labelled measurement after the headline one: the same step in another precision / batch
     (fp16 at batch 256 = the mode inside north_star's 1e-3; fp8 at batch 512 = BASELINE configs[4])."""
-    from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
+    from implementation_phd_lab_vision_amd.backbone import BackboneLanes, ResNet50Backbone
     from implementation_phd_lab_vision_amd.weights import synthetic_frames
-    bb = ResNet50Backbone(state_dict=sd, max_batch=batch, precision=precision).to(dev).eval()
+    lanes = lanes_obj = None
+    if n_lanes > 1:                       # the headline's execution mode: steps dealt round robin over the lanes; lane 0 alone for the checks / profile
+        lanes = BackboneLanes(lanes=n_lanes, state_dict=sd, max_batch=batch, precision=precision).to(dev).eval()
+        bb = lanes.lane0
+    else:
+        bb = ResNet50Backbone(state_dict=sd, max_batch=batch, precision=precision).to(dev).eval()
     try:
         x = synthetic_frames(batch, seed=1234).to(dev)
-        feats = torch.empty((batch, 2048), dtype=torch.float32, device=dev)
+        feats_l = [torch.empty((batch, 2048), dtype=torch.float32, device=dev) for _ in range(max(1, n_lanes))]
+        feats = feats_l[0]
+        state = {"k": 0}
 
         def step():
-            bb.features(x, out=feats)
+            if lanes is None:
+                bb.features(x, out=feats)
+            else:
+                lanes.submit(x, out=feats_l[state["k"] % n_lanes])
+                state["k"] += 1
 
         def fence():
             torch.cuda.synchronize(dev)
 
         elapsed, pre = timed_steps(step, fence, steps, warmup, preheat_s, batch)
+        lanes_equal = all(bool(torch.equal(feats_l[0], f)) for f in feats_l[1:]) if lanes is not None else None
+        single = None
+        if lanes is not None:
+            lanes, lanes_obj = None, lanes        # from here on: lane 0 alone (the single-lane figure, the batch-2 check, the event profile)
+            el1, _ = timed_steps(step, fence, steps, 1, min(preheat_s, 0.3), batch)
+            single = {"value": batch * steps / el1, "unit": "frames/s", "ms_per_step": 1e3 * el1 / steps}
         if not bool(torch.isfinite(feats).all()):
             raise SystemExit(f"bench.py: non-finite features in the {precision} secondary run")
         small = bb.features(x[:2].contiguous())
@@ -164,7 +181,8 @@ def secondary_mode(precision: str, batch: int, steps: int, warmup: int, preheat_
         peak = MFMA_FP8_PEAK_TFLOPS if precision == "fp8" else MFMA_BF16_PEAK_TFLOPS
         # fp8 mode: layer1's three 3x3 convs run in 16 bits inside the same class; their flops are priced at the fp8 peak too (conservative)
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-        out = {"secondary": True, "precision": precision, "batch": batch, "steps": steps, "value": batch * steps / elapsed,
+        out = {"secondary": True, "precision": precision, "batch": batch, "steps": steps, "lanes": max(1, n_lanes), "single_lane": single,
+               "lanes_equal": lanes_equal, "value": batch * steps / elapsed,
                "unit": "frames/s", "ms_per_step": 1e3 * elapsed / steps, "preheat_frames_per_s": pre,
                "tflops": batch * steps / elapsed * GFLOP_PER_FRAME / 1e3,
                "igemm": {"achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
@@ -176,7 +194,7 @@ def secondary_mode(precision: str, batch: int, steps: int, warmup: int, preheat_
             acc_in["scales"] = list(bb.fp8_scales)
         return out, acc_in
     finally:
-        bb.close()
+        (lanes_obj or lanes or bb).close()
 
 
 def main() -> None:
@@ -536,7 +554,7 @@ def main() -> None:
         (lanes or bb).close()         # frees the headline handles' workspaces before the secondary ones are created
         torch.cuda.empty_cache()
         for prec, b in (("fp16", 256), ("fp8", 512)):
-            secondary[f"{prec}_b{b}"], acc_in[prec] = secondary_mode(prec, b, args.steps, args.warmup, min(args.preheat, 0.5), dev, sd)
+            secondary[f"{prec}_b{b}"], acc_in[prec] = secondary_mode(prec, b, args.steps, args.warmup, min(args.preheat, 0.5), dev, sd, n_lanes)
 
     cpu = None
     accuracy = None

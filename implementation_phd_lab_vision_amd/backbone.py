@@ -334,11 +334,50 @@ class BackboneLanes:
             bb.to(device, share_from=share)
         self._device = self._bbs[0]._device
         if len(self._streams) != len(self._bbs):
-            self._streams = [torch.cuda.Stream(self._device) for _ in self._bbs]
+            self._streams = self._pick_streams(len(self._bbs))
         if self._bbs[0]._precision == PREC_FP8:      # one calibration for all lanes: the features must not depend on the lane
             for bb in self._bbs[1:]:
                 bb.set_fp8_scales(self._bbs[0].fp8_scales)
         return self
+
+    # ---- streams that really run side by side ------------------------------------------------
+    @staticmethod
+    def _overlap(a: "torch.cuda.Stream", b: "torch.cuda.Stream", dev: torch.device, cycles: int = 1_500_000) -> bool:
+        """Do kernels on ``a`` and ``b`` execute concurrently?  Two spin kernels, one per stream, against the same two on one stream."""
+        import time
+        torch.cuda._sleep(1000)                                  # (first use compiles / loads the spin kernel)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(cycles)
+            torch.cuda._sleep(cycles)
+        torch.cuda.synchronize(dev)
+        serial = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(cycles)
+        with torch.cuda.stream(b):
+            torch.cuda._sleep(cycles)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) < 0.75 * serial
+
+    def _pick_streams(self, n: int):
+        """One HIP stream per lane, checked to overlap: the runtime multiplexes HIP streams onto a few hardware queues in creation order, and two
+        streams that land on the SAME queue run their kernels strictly one after the other -- measured: one stream pair in eight of a process
+        (profiles/r03_lanes_ab.txt), the whole two-lane gain gone.  A candidate that does not overlap with the lanes chosen so far is replaced by
+        the next stream of PyTorch's pool (it never has to be: correctness does not depend on it, only the gain does)."""
+        dev = self._device
+        streams = [torch.cuda.Stream(dev)]
+        self.stream_retries = 0
+        for _ in range(1, n):
+            cand = torch.cuda.Stream(dev)
+            for _attempt in range(24):
+                if all(self._overlap(s, cand, dev) for s in streams):
+                    break
+                self.stream_retries += 1
+                cand = torch.cuda.Stream(dev)
+            streams.append(cand)
+        return streams
 
     def cuda(self, device=None) -> "BackboneLanes":
         return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))

@@ -504,6 +504,7 @@ def test_backbone_lanes_give_the_bits_of_one_backbone():
         xs = [synthetic_frames(n, seed=900 + n).to(dev) for n in (24, 5, 17, 24, 9)]
         refs = [one.features(x).clone() for x in xs]
         torch.cuda.synchronize(dev)
+        assert BackboneLanes._overlap(two._streams[0], two._streams[1], dev), "the two lanes' streams share a hardware queue"
         tickets = [two.submit(x) for x in xs]              # five batches queued before the first result is looked at
         assert [t.lane for t in tickets] == [0, 1, 0, 1, 0]
         for t, r in zip(tickets, refs):
