@@ -484,7 +484,7 @@ def main() -> None:
                 traffic = None
         traffic_source = (f"profiles/{tpath.name} (rocprofv3 --pmc passes of this build on ANOTHER box of the pool, static; not measured in this run)"
                           if tpath is not None else None)
-        roofline = {"bound": "mfma", "kernel": "igemm_bf16_kernel + igemm_ws_kernel + conv3x3_c64_kernel + conv3x3_xres_kernel (%d conv launches/step)" % round(ig["launches"] / max(1, args.steps)), "achieved": achieved,
+        roofline = {"bound": "mfma", "kernel": "igemm_bf16_kernel + igemm_ws_kernel + conv3x3_xres_kernel + conv3x3_s2_kernel (%d conv launches/step: every conv that is a launch of its own)" % round(ig["launches"] / max(1, args.steps)), "achieved": achieved,
                     "peak": (MFMA_FP8_PEAK_TFLOPS if args.precision == "fp8" else MFMA_BF16_PEAK_TFLOPS), "unit": "TFLOP/s",
                     "frac": achieved / (MFMA_FP8_PEAK_TFLOPS if args.precision == "fp8" else MFMA_BF16_PEAK_TFLOPS),
                     "traffic": traffic, "traffic_source": traffic_source,
