@@ -145,6 +145,8 @@ def secondary_mode(precision: str, batch: int, steps: int, warmup: int, preheat_
         bb = ResNet50Backbone(state_dict=sd, max_batch=batch, precision=precision).to(dev).eval()
     try:
         x = synthetic_frames(batch, seed=1234).to(dev)
+        if lanes is not None:
+            lanes.tune(x, min_gain=1.01)
         feats_l = [torch.empty((batch, 2048), dtype=torch.float32, device=dev) for _ in range(max(1, n_lanes))]
         feats = feats_l[0]
         state = {"k": 0}
@@ -367,6 +369,7 @@ def main() -> None:
             if dist is not None:
                 gather_feats()
     elif lanes is not None:
+        lane_gain = lanes.tune(x)          # the lanes' streams really run side by side (changed if not); untimed, results unaffected
         lane_state = {"k": 0, "free": [None] * n_lanes}
 
         def step():
@@ -588,7 +591,7 @@ def main() -> None:
                                    f"(BASELINE configs[{4 if args.precision == 'fp8' else 1}]), seeded synthetic weights, (N,2048) fp32 features"
                                    + (", RCCL gather to rank 0" if dist_used else ""),
                        "batch_per_gpu": args.batch, "micro_batch": args.micro_batch,
-                       "lanes": n_lanes, "lanes_note": (f"{n_lanes} independent batches in flight, each on its own backbone copy + HIP stream (steps dealt round robin; "
+                       "lanes": n_lanes, "lanes_tune": (getattr(lanes, "tune_log", None) if lanes is not None else None), "lanes_note": (f"{n_lanes} independent batches in flight, each on its own backbone copy + HIP stream (steps dealt round robin; "
                                                         "every step is a whole batch-%d forward; nothing is shared or skipped)" % args.batch) if n_lanes > 1 else "one batch at a time",
                        "input": args.input + (" from pinned host memory every step (PCIe-inclusive, H2D overlapped)" if args.from_host else ""),
                        "parallelism": f"frames sharded over {world} rank(s)"},

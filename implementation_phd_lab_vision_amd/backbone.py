@@ -379,6 +379,54 @@ class BackboneLanes:
             streams.append(cand)
         return streams
 
+    def tune(self, x: torch.Tensor, steps: int = 8, tries: int = 4, min_gain: float = 1.02) -> float:
+        """Check with the REAL workload that the lanes run side by side, and change streams if they do not.  The spin-kernel check of
+        ``_pick_streams`` is necessary but was seen not to be sufficient (one bench.py process in ~10 still showed two lanes = one lane:
+        how the firmware maps the runtime's queues onto the hardware is not ours to see).  ``steps`` forwards of ``x`` on lane 0 alone against
+        ``steps`` forwards dealt over the lanes; below ``min_gain`` the lanes behind the first get new streams (again checked with the spin
+        kernels) and the measurement is repeated, ``tries`` times at most.  Returns the last ratio measured (two lanes / one).  Costs
+        ~2 x steps forwards per try; never affects results."""
+        import time
+        if len(self._bbs) < 2:
+            return 1.0
+        dev = self._device
+        outs = [torch.empty((x.shape[0], FEATURE_DIM), dtype=torch.float32, device=dev) for _ in self._bbs]
+
+        def run(lanes: bool) -> float:
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for k in range(steps):
+                if lanes:
+                    self.submit(x, out=outs[k % len(outs)])
+                else:
+                    self._bbs[0].features(x, outs[0])
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t0
+
+        run(True); run(False)                      # warm both paths
+        ratio = 1.0
+        self.tune_log = []
+        for attempt in range(tries):
+            t1 = min(run(False), run(False))
+            t2 = min(run(True), run(True))
+            ratio = t1 / t2
+            self.tune_log.append(round(ratio, 4))
+            if ratio >= min_gain:
+                break
+            if attempt + 1 < tries:
+                keep = self._streams[0]
+                new = [keep]
+                for _ in self._streams[1:]:
+                    cand = torch.cuda.Stream(dev)
+                    for _a in range(24):
+                        if all(self._overlap(s, cand, dev) for s in new):
+                            break
+                        cand = torch.cuda.Stream(dev)
+                    new.append(cand)
+                self._streams = new
+        self._next = 0
+        return ratio
+
     def cuda(self, device=None) -> "BackboneLanes":
         return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
 

@@ -421,6 +421,9 @@ def main(argv: Optional[List[str]] = None) -> None:
     for _ in range(n_lanes):
         backbone(warm)
     torch.cuda.synchronize(device)
+    if n_lanes > 1:
+        gain = backbone.tune(warm)
+        log(f"Lanes      : {n_lanes} lanes run at {gain:.3f} x one lane on the warm-up batch")
     del warm
     log("✓ Warmup complete\n")
 

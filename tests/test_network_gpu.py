@@ -505,6 +505,8 @@ def test_backbone_lanes_give_the_bits_of_one_backbone():
         refs = [one.features(x).clone() for x in xs]
         torch.cuda.synchronize(dev)
         assert BackboneLanes._overlap(two._streams[0], two._streams[1], dev), "the two lanes' streams share a hardware queue"
+        gain = two.tune(xs[0], steps=3, tries=2)           # workload check of the lanes' streams (may swap them): a ratio, results unaffected
+        assert 0.5 < gain < 3.0 and len(two.tune_log) >= 1
         tickets = [two.submit(x) for x in xs]              # five batches queued before the first result is looked at
         assert [t.lane for t in tickets] == [0, 1, 0, 1, 0]
         for t, r in zip(tickets, refs):
