@@ -105,16 +105,20 @@ int r50_forward_layer(r50_handle* h, const float* x_nchw_f32_dev, int n, const c
  * "overlap_ds" (1 = downsample convs on a side stream; default 0), "fused_stem" (default 1),
  * "fuse_tail" (layer1 / layer2: conv3 + identity + ReLU + the next block's conv1 in one kernel; default 1),
  * "fuse_tail3" (layer3.1-.4: the same pair chained through LDS in one launch; default 1; needs "fuse_tail"),
- * "fuse_block1" (layer1.1: the same for the 56x56 body, bneck_block1_kernel; 2 = layer1.2 as well; default 1; needs "fuse_tail"; same bits),
+ * "fuse_block1" (layer1: the same for the 56x56 body, bneck_block1_kernel; 1 = layer1.1, 2 = layer1.2 as well, 3 = layer1.0 too, with its
+ * downsample conv computed in the kernel; default 3; needs "fuse_tail"; same bits),
+ * "fuse_cat_chain" (layer2.0: conv3 + downsample + ReLU as one two-source conv chained with layer2.1.conv1 in one launch,
+ * bneck_catchain_kernel; default 1; same bits),
  * "fuse_block2" (layer2.1-.3: conv2 + conv3 + identity + ReLU [+ the next conv1] in one launch, t2 kept in LDS; default 1; needs
  * "fuse_tail"; same bits),
  * "fuse_fp8_handover" (R50_PREC_FP8: layer1's output quantised to e4m3 in layer1.2.conv3's epilogue instead of in a pass of its
  * own; default 1; same bits either way),
  * "tile" (force an igemm tile id for every conv, 0 = tuned table; also turns "fuse_tail" off),
  * measurement knobs, all results bit-identical: "inplace_out" (1 = plain-identity blocks write their output over their input;
- * default 0), and two PROCESS-WIDE ones: "cu_cap" (workgroups a persistent launch may use, 0 = every CU; for pipelines that share
- * the chip) and "xres_variant" (schedule of the input-resident 3x3 kernel: 0 = default, 5 = mid-step barrier, 6 = + deeper weight
- * ring, 7 = deeper ring only). */
+ * default 0), and PROCESS-WIDE ones (they apply to every handle of the process): "cu_cap" (workgroups a persistent launch may use,
+ * 0 = every CU; for pipelines that share the chip), "xres_variant" (schedule of the input-resident 3x3 kernel: 0 = default, 5 = mid-step
+ * barrier, 6 = + deeper weight ring, 7 = deeper ring only), "tail3_variant" (kernel of the chained layer3 tail: 0 = bneck_tail3_kernel,
+ * 1 = bneck_tail3p_kernel, the default, 2 = the same with 98-row LDS slots) and "tail3_bp" (its real pixels per tile, 0 = automatic). */
 int r50_set_option(r50_handle* h, const char* key, int64_t value);
 int r50_get_option(r50_handle* h, const char* key, int64_t* value);
 
