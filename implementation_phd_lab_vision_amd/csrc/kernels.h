@@ -2927,7 +2927,9 @@ __global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
 #ifndef T3P_PDB
 #define T3P_PDB 6
 #endif
-template <int ET, int ROWS>
+// NOB (layer3.5, whose next conv1 is layer4.0's 1024 -> 512 and does not fit the chain): group B only copies out_c out -- conv3 + identity + ReLU of
+// the stage's last block through the same pipeline, no second GEMM, no y1n (the weight stream's W1 slices are never read).
+template <int ET, int ROWS, bool NOB = false>
 __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int CMID = 256, COUT = 1024, C1N = 256;
@@ -3165,8 +3167,10 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
                     if (!(T3P_ABL & 2) || o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, voff, 0, 0);
                 }
         };
-        w_load_half(0, 4, wA, 0); w_load_half(0, 4, wA, 1);
-        w_load_half(1, 4, wB, 0); w_load_half(1, 4, wB, 1);
+        if constexpr (!NOB) {
+            w_load_half(0, 4, wA, 0); w_load_half(0, 4, wA, 1);
+            w_load_half(1, 4, wB, 0); w_load_half(1, 4, wB, 1);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();             // P
         if (T3P_PRIO & 1) __builtin_amdgcn_s_setprio(1);
@@ -3175,11 +3179,11 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
         R50_STAMP_DECL
         for (int tile = first; tile < a.n_tiles; tile += grid) {
             // ---- first interval (group A is on chunk 0): the previous tile's y1n leaves, the accumulators restart at b1
-            if (prev >= 0) y1n_store(prev);
+            if (!NOB && prev >= 0) y1n_store(prev);
             prev = tile;
             tile_rows(tile);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {         // accB[2t + e]: channels 128t + 32w + 8fq + 4e ..
+            for (int t = 0; t < (NOB ? 0 : 2); ++t) {         // accB[2t + e]: channels 128t + 32w + 8fq + 4e ..
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + B1_OFF + (128 * t + 32 * w + 8 * fq) * 4);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + B1_OFF + (128 * t + 32 * w + 8 * fq + 4) * 4);
 #pragma unroll
@@ -3193,10 +3197,12 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
                 using PB = std::integral_constant<int, T3P_PDB>;
                 using W2 = std::integral_constant<int, 2>;
                 using XP = std::integral_constant<bool, (T3P_XPRE & 2) != 0>;
-                w_step(PB{}, W2{}, NO{}, XP{}, g + 0, 4, wA, xb, xb, accB[0], accB[1], xq);
-                w_step(PB{}, W2{}, XP{}, XP{}, g + 1, 4, wB, xb, xb + SLOT, accB[2], accB[3], xq);
-                w_step(PB{}, W2{}, XP{}, XP{}, g + 2, 4, wA, xb + SLOT, xb + SLOT, accB[0], accB[1], xq);
-                w_step(PB{}, W2{}, XP{}, NO{}, g + 3, 4, wB, xb + SLOT, xb, accB[2], accB[3], xq);
+                if constexpr (!NOB) {
+                    w_step(PB{}, W2{}, NO{}, XP{}, g + 0, 4, wA, xb, xb, accB[0], accB[1], xq);
+                    w_step(PB{}, W2{}, XP{}, XP{}, g + 1, 4, wB, xb, xb + SLOT, accB[2], accB[3], xq);
+                    w_step(PB{}, W2{}, XP{}, XP{}, g + 2, 4, wA, xb + SLOT, xb + SLOT, accB[0], accB[1], xq);
+                    w_step(PB{}, W2{}, XP{}, NO{}, g + 3, 4, wB, xb + SLOT, xb, accB[2], accB[3], xq);
+                }
                 g += 4;
 #if defined(R50_STAMP)
                 __builtin_amdgcn_sched_barrier(0);
@@ -3220,7 +3226,7 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
                 R50_MARK(4)                       // chunk barrier
             }
         }
-        if (prev >= 0) y1n_store(prev);
+        if (!NOB && prev >= 0) y1n_store(prev);
         R50_STAMP_FLUSH(8)
     }
 #else

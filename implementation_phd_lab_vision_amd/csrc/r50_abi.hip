@@ -69,6 +69,7 @@ struct r50_handle {
     int fuse_fp8_handover = 1;          // fp8 mode: quantise layer1's output in layer1.2.conv3's epilogue instead of in a pass of its own
     int fuse_tail3 = 1;                 // layer3.1-.4: conv3 + identity + ReLU chained with the next block's conv1 through LDS (bneck_tail3_kernel)
     __bf16* catchain_wp = nullptr;      // layer2.0: [W3 | Wd] and layer2.1.conv1 in bneck_catchain_kernel's fragment-ordered stream
+    int fuse_tail3_last = 1;            // layer3.5: conv3 + identity + ReLU through the pipelined tail kernel without a second GEMM
     int fuse_cat_chain = 1;             // layer2.0: conv3 + downsample + ReLU chained with layer2.1.conv1 in one launch (bneck_catchain_kernel)
     __bf16* tail3_wp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per layer3 block b: [W3(b) | W1(b+1)] in the kernel's fragment order
     int fuse_block1 = 3;                // 1: layer1.1, 2 (default since round 3: with the loaders' position loop unrolled the c1 = 128 form takes 248 us against
@@ -794,8 +795,10 @@ hipError_t pack_tail3_weights(const void* w3, const void* w1, void* wp, hipStrea
 int g_tail3_bp = 0;        // option "tail3_bp": real pixels per tile of the chained layer3 tail (0 = whole rounds of the chip: 98 at batch 256)
 int g_tail3_variant = [] { const char* v = std::getenv("R50_TAIL3_VAR"); return v ? std::atoi(v) : 1; }();
 hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const float* b3, const void* res, void* out,
-                              const float* b1, void* y1n, hipStream_t s, int et = 0, int bp_override = 0, int variant = -1) {
+                              const float* b1, void* y1n, hipStream_t s, int et = 0, int bp_override = 0, int variant = -1, bool no_next = false) {
+    if (no_next) { b1 = b3; y1n = out; }       // conv3 + identity + ReLU only (pipelined kernel, group B copies out): b1 / y1n are not used
     if (variant < 0) variant = g_tail3_variant;
+    if (no_next) variant = 1;       // conv3 + identity + ReLU only (pipelined kernel, group B copies out): b1 / y1n are not used
     if (bp_override == 0) bp_override = g_tail3_bp;
     if (!y2 || !wp || !b3 || !res || !out || !b1 || !y1n || m <= 0 || m * 2048 >= (1ll << 31)) return hipErrorInvalidValue;
     if (g_num_cus == 0) {
@@ -826,7 +829,8 @@ hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const
     if (variant == 1 || variant == 2) {
         const size_t ldsp = 8 * (size_t)rows * 128 + 256 * 4 + 1024 * 4;      // t2 (4 slots) + out_c (2 x 2) + b1 + b3
         void (*kp)(const Tail3Args);
-        if (variant == 1) kp = et == 1 ? bneck_tail3p_kernel<1, 112> : bneck_tail3p_kernel<0, 112>;
+        if (no_next) kp = et == 1 ? bneck_tail3p_kernel<1, 112, true> : bneck_tail3p_kernel<0, 112, true>;
+        else if (variant == 1) kp = et == 1 ? bneck_tail3p_kernel<1, 112> : bneck_tail3p_kernel<0, 112>;
         else kp = et == 1 ? bneck_tail3p_kernel<1, 98> : bneck_tail3p_kernel<0, 98>;
         hipError_t ep = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
         if (ep != hipSuccess) return ep;
@@ -1467,6 +1471,19 @@ after_pool:
                 rc = run_conv_cat(h, si, c3, *cdp, buf[fr[1]], buf[cur], n, h2, w2, hh, ww, outb, s);
                 if (rc) return rc;
                 h3 = h2; w3 = w2;
+            } else if (si == 2 && b == blocks - 1 && b < 8 && h->tail3_wp[b] && h->fuse_tail3 && h->fuse_tail3_last && h->fuse_tail && !split && !tap && h->tile_override == 0 &&
+                       (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16) && c3.ks == 1 && c3.cin == 256 && c3.cout == 1024 && idn == buf[cur] &&
+                       g_tail3_variant >= 1) {
+                // layer3.5: conv3 + identity + ReLU through the pipelined tail kernel without a second GEMM (its next conv1, layer4.0's 1024 -> 512, does
+                // not fit the chain): same bits as the igemm launch, whose K = 256 tiles alternate between an MFMA phase and an epilogue phase
+                const long long m = (long long)n * h2 * w2;
+                EvRec rt{};
+                prof_begin(h, s, rt, PC_TAIL3, 2.0 * m * (double)c3.cout * c3.cin, 2.0 * (m * ((double)c3.cin + 2.0 * c3.cout) + (double)c3.cout * c3.cin),
+                           (int)(&c3 - &h->convs[0]));
+                e = launch_bneck_tail3(buf[fr[1]], m, h->tail3_wp[b], c3.bias, idn, outb, nullptr, nullptr, s, et, 0, -1, /*no_next=*/true);
+                prof_end(h, s, rt);
+                if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_tail3 (no next conv1) launch (" + c3.conv_key + "): " + hipGetErrorString(e));
+                h3 = h2; w3 = w2;
             } else {
                 // fp8 mode, layer1's last conv: the hand-over to the fp8 stack (quantisation with the first activation scale) is folded into
                 // this conv's epilogue -- the 16-bit tensor is neither written nor read back (unless a tap asks for it)
@@ -1783,6 +1800,10 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
                     if (c3.ks == 1 && c3.cin == 256 && c3.cout == 1024 && nx.ks == 1 && nx.stride == 1 && nx.cin == 1024 && nx.cout == 256) {
                         if (!h->tail3_wp[b]) HIP_TRY(h, hipMalloc((void**)&h->tail3_wp[b], kTail3PackedBytes));
                         HIP_TRY(h, pack_tail3_weights(c3.w, nx.w, h->tail3_wp[b], nullptr));
+                    } else if (b == blocks - 1 && c3.ks == 1 && c3.cin == 256 && c3.cout == 1024) {
+                        // the stage's last block: conv3 + identity + ReLU alone through the pipelined kernel (its W1 slices are never read: W3 stands in)
+                        if (!h->tail3_wp[b]) HIP_TRY(h, hipMalloc((void**)&h->tail3_wp[b], kTail3PackedBytes));
+                        HIP_TRY(h, pack_tail3_weights(c3.w, c3.w, h->tail3_wp[b], nullptr));
                     }
                 }
                 li += (b == 0) ? 4 : 3;
@@ -1889,6 +1910,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "fuse_tail") h->fuse_tail = value ? 1 : 0;
     else if (k == "fuse_tail3") h->fuse_tail3 = value ? 1 : 0;
     else if (k == "fuse_cat_chain") h->fuse_cat_chain = value ? 1 : 0;
+    else if (k == "fuse_tail3_last") h->fuse_tail3_last = value ? 1 : 0;
     else if (k == "tail3_bp") { if (value < 0 || value > 112) return fail(h, R50_ERR_INVALID, "tail3_bp must be 0 .. 112"); g_tail3_bp = (int)value; }
     else if (k == "tail3_variant") { if (value < 0 || value > 2) return fail(h, R50_ERR_INVALID, "tail3_variant must be 0, 1 or 2"); g_tail3_variant = (int)value; }
     else if (k == "fuse_fp8_handover") h->fuse_fp8_handover = value ? 1 : 0;
@@ -1927,6 +1949,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "tail3_variant") *value = g_tail3_variant;
     else if (k == "tail3_bp") *value = g_tail3_bp;
     else if (k == "fuse_cat_chain") *value = h->fuse_cat_chain;
+    else if (k == "fuse_tail3_last") *value = h->fuse_tail3_last;
     else if (k == "fuse_fp8_handover") *value = h->fuse_fp8_handover;
     else if (k == "fuse_stem_c1") *value = h->fuse_stem_c1;
     else if (k == "fuse_ds_cat") *value = h->fuse_ds_cat;
@@ -2065,6 +2088,16 @@ int r50_op_bneck_tail(const void* y2, int64_t m, int cmid, const void* w3, const
     hipError_t e;
     if (cmid == 64) e = launch_bneck_tail(y2, m, w3, b3, res, wd, bd, out, w1, c1, b1, y1n, (hipStream_t)stream);
     else if (cmid == 128 && c1 == 128 && !wd && !bd) e = launch_bneck_tail2(y2, m, w3, b3, res, out, w1, b1, y1n, (hipStream_t)stream);
+    else if (cmid == 256 && c1 == 0 && !w1 && !b1 && !y1n && !wd && !bd) {
+        // conv3 + identity + ReLU alone through the pipelined layer3 tail (the form layer3.5 runs in the network): W3 stands in for the unused W1 slices
+        void* wp_scratch = nullptr;
+        if (hipMallocAsync(&wp_scratch, kTail3PackedBytes, (hipStream_t)stream) != hipSuccess || !wp_scratch)
+            return fail(nullptr, R50_ERR_HIP, "r50_op_bneck_tail: hipMallocAsync");
+        e = pack_tail3_weights(w3, w3, wp_scratch, (hipStream_t)stream);
+        if (e == hipSuccess) e = launch_bneck_tail3(y2, m, wp_scratch, b3, res, out, nullptr, nullptr, (hipStream_t)stream, 0, 0, -1, /*no_next=*/true);
+        const hipError_t ef = hipFreeAsync(wp_scratch, (hipStream_t)stream);
+        if (e == hipSuccess) e = ef;
+    }
     else if (cmid == 256 && c1 == 256 && !wd && !bd) {
         const char* v = std::getenv("R50_TAIL3_BP");          // test / A-B knob of this debug hook: real pixels per tile (1..112); unset = automatic
         const char* vv = std::getenv("R50_TAIL3_VAR");        // kernel variant (launch_bneck_tail3), read per call so that one process can A/B

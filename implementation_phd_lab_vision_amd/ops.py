@@ -177,6 +177,23 @@ def bneck_tail_bf16(y2: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, identi
     return out, y1n
 
 
+def conv3_identity_tail3_bf16(y2: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, identity: torch.Tensor) -> torch.Tensor:
+    """``relu(conv3(y2) + b3 + identity)`` of a layer3 block (y2 (...,256), w3 (1024,256), identity (...,1024)) through the pipelined tail kernel
+    WITHOUT a next conv1 (``r50_op_bneck_tail`` with c1 = 0): the form the stage's last block, layer3.5, runs in."""
+    for t, n in ((y2, "y2"), (w3, "w3"), (identity, "identity")):
+        _need(t, torch.bfloat16, n)
+    _need(b3, torch.float32, "b3")
+    m = y2.numel() // 256
+    if y2.shape[-1] != 256 or tuple(w3.shape) != (1024, 256) or identity.numel() != m * 1024 or b3.numel() != 1024:
+        raise ValueError("conv3_identity_tail3_bf16: inconsistent shapes")
+    out = torch.empty(tuple(y2.shape[:-1]) + (1024,), dtype=torch.bfloat16, device=y2.device)
+    with torch.cuda.device(y2.device):
+        rc = _lib.load_library().r50_op_bneck_tail(y2.data_ptr(), m, 256, w3.data_ptr(), b3.data_ptr(), identity.data_ptr(), None, None,
+                                                   out.data_ptr(), None, 0, None, None, _stream(y2))
+    _lib.check(rc, None, "r50_op_bneck_tail")
+    return out
+
+
 def bneck_block2_bf16(t1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, identity: torch.Tensor,
                       w1: Optional[torch.Tensor] = None, b1: Optional[torch.Tensor] = None):
     """Layer2 bottleneck body in one launch (``r50_op_bneck_block2``): t1 (N,28,28,128), identity (N,28,28,512) bf16 NHWC; w2 (128,3,3,128),

@@ -107,6 +107,8 @@ int r50_forward_layer(r50_handle* h, const float* x_nchw_f32_dev, int n, const c
  * "fuse_tail3" (layer3.1-.4: the same pair chained through LDS in one launch; default 1; needs "fuse_tail"),
  * "fuse_block1" (layer1: the same for the 56x56 body, bneck_block1_kernel; 1 = layer1.1, 2 = layer1.2 as well, 3 = layer1.0 too, with its
  * downsample conv computed in the kernel; default 3; needs "fuse_tail"; same bits),
+ * "fuse_tail3_last" (layer3.5, whose next conv1 does not fit the chain: conv3 + identity + ReLU alone through the pipelined tail kernel; default 1;
+ * same bits),
  * "fuse_cat_chain" (layer2.0: conv3 + downsample + ReLU as one two-source conv chained with layer2.1.conv1 in one launch,
  * bneck_catchain_kernel; default 1; same bits),
  * "fuse_block2" (layer2.1-.3: conv2 + conv3 + identity + ReLU [+ the next conv1] in one launch, t2 kept in LDS; default 1; needs
@@ -202,7 +204,9 @@ int r50_op_maxpool(const void* x_nhwc_bf16, int n, int h, int w, int c, void* y_
  * weights folded (cout, cin) K-contiguous, biases fp32.  cmid = 64 reproduces the two separate launches bit
  * for bit; cmid = 128 sums the second conv's K in eight slices (fp32), i.e. within rounding of them; cmid = 256
  * (c1 = 256, layer3: the chained kernel, weights packed into fragment order per call by this hook) is bit for
- * bit again.  (Environment R50_TAIL3_BP = 1..112: pixels per tile of the cmid = 256 kernel, a test knob.) */
+ * bit again.  cmid = 256 with c1 = 0 and w1 = b1 = y1n = NULL: conv3 + identity + ReLU ALONE through the same pipelined kernel (the form the
+ * stage's last block, layer3.5, runs in; bit for bit a 1x1 r50_op_conv2d with a residual).  (Environment R50_TAIL3_BP = 1..112: pixels per tile
+ * of the cmid = 256 kernel, R50_TAIL3_VAR = 0..2: its variant; test knobs.) */
 int r50_op_bneck_tail(const void* y2_bf16, int64_t m, int cmid, const void* w3_bf16, const float* b3,
                       const void* identity_bf16, const void* wd_bf16, const float* bd, void* out_bf16, const void* w1_bf16,
                       int c1, const float* b1, void* y1n_bf16, void* stream);

@@ -443,6 +443,21 @@ def test_bneck_cat_chain_equals_the_two_launches(lib_built, n):
         _check_bf16(y1n, y1_ref, "bneck_cat_chain y1n")
 
 
+@pytest.mark.parametrize("n", [1, 5, 256], ids=lambda v: "n%d" % v)
+def test_layer3_last_block_conv3_through_the_pipelined_tail(lib_built, n):
+    """layer3.5: conv3 + identity + ReLU through bneck_tail3p_kernel<.., NOB> (no second GEMM; group B only copies out_c out) -- bit for bit the
+    igemm launch with a residual it replaces; nothing written past M."""
+    from implementation_phd_lab_vision_amd import ops
+    y2, w3, b3, idn, _w1, _b1 = _tail3_inputs(n, 14, 14, 4100 + n)
+    d = _dev()
+    y2d = y2.permute(0, 2, 3, 1).contiguous().to(d)
+    idd = idn.permute(0, 2, 3, 1).contiguous().to(d)
+    w3d, b3d = w3.view(1024, 256).contiguous().to(d), b3.to(d)
+    out = ops.conv3_identity_tail3_bf16(y2d, w3d, b3d, idd)
+    out_u = ops.conv2d_bf16(y2d, w3d.view(1024, 1, 1, 256), b3d, relu=True, residual=idd)
+    assert torch.equal(out, out_u)
+
+
 FP16_CASES = [CONV_CASES[i] for i in (1, 2, 3, 5, 6, 10, 12)]
 
 
