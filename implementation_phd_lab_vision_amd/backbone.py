@@ -489,6 +489,10 @@ class BackboneLanes:
                 after.record(torch.cuda.current_stream(self._device))
         if after is not None:
             st.wait_event(after)
+        # allocator bookkeeping: both tensors are used on the lane's stream, whichever stream they were allocated on (e.g. a prefetcher's copy
+        # stream) -- their blocks must not be handed out again before the lane's kernels are done
+        x.record_stream(st)
+        out.record_stream(st)
         with torch.cuda.stream(st):
             (bb.features_u8 if u8 else bb.features)(x, out)
             done = torch.cuda.Event()

@@ -76,7 +76,7 @@ def build_parser() -> argparse.ArgumentParser:
                         "once more, like the reference's warm-up batch, :235-245); noise = 8 synthetic uniform-noise frames (scales that fit "
                         "noise, not H36M crops: anything above 448 x scale clips silently)")
     p.add_argument("--lanes", type=int, default=2,
-                   help="Backbone copies on their own HIP streams (backbone.BackboneLanes): under --augment the variants of a batch are "
+                   help="Backbone copies on their own HIP streams (backbone.BackboneLanes): the variants of a batch and consecutive batches are "
                         "independent forward passes and two are kept in flight (same bits, +5 %% frames/s); 1 = one stream")
     p.add_argument("--micro-batch", type=int, default=0, help="Frames per pass through the layer stack (0 = auto)")
     p.add_argument("--max-batch", type=int, default=256, help="Frames per backbone call chunk (workspace size)")
@@ -196,8 +196,30 @@ def _resolve_device(name: str, ctx: D.RankContext) -> torch.device:
     return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
 
 
+class PendingFeatures:
+    """The forward passes of one batch, submitted but not waited for (``submit_features``); ``result()`` orders the current stream behind
+    them and returns (B, V, T, 2048)."""
+
+    def __init__(self, per_variant, pending):
+        self._per_variant, self._pending = per_variant, pending
+
+    def result(self) -> torch.Tensor:
+        pv = self._per_variant
+        for slot, ticket, _x, (b, t) in self._pending:
+            pv[slot] = ticket.wait().view(b, t, -1)
+        self._pending = []
+        pv = [pv[0].flip(1) if isinstance(v, str) else v for v in pv]
+        return torch.stack(pv, dim=1)
+
+
 def extract_features(backbone: Callable[[torch.Tensor], torch.Tensor], variants_batch, device: torch.device,
                      reuse_trev: bool = True) -> torch.Tensor:
+    """``submit_features(...).result()``: the reference's call site as one blocking call."""
+    return submit_features(backbone, variants_batch, device, reuse_trev).result()
+
+
+def submit_features(backbone: Callable[[torch.Tensor], torch.Tensor], variants_batch, device: torch.device,
+                    reuse_trev: bool = True) -> PendingFeatures:
     """The hot call site (:287-297): every variant's (B,T,3,224,224) clip batch -> (B,T,2048) fp32.
     Returns (B, V, T, 2048) on ``device``.
 
@@ -208,7 +230,9 @@ def extract_features(backbone: Callable[[torch.Tensor], torch.Tensor], variants_
     takes part in the check, per batch).
 
     The variants are independent forward passes: a backbone with lanes (``backbone.BackboneLanes``: has ``submit``) gets all of
-    them submitted before the first result is waited for, so two are in flight at a time (same bits, +5 % frames/s)."""
+    them submitted before the first result is waited for, so two are in flight at a time (same bits, +5 % frames/s).  And nothing is
+    waited for HERE: ``run_extraction`` submits round q + 1 before it asks for round q's ``result()``, so that without ``--augment`` (one
+    forward pass per batch) consecutive batches share the two lanes the same way."""
     per_variant = []
     lanes = hasattr(backbone, "submit") and device.type == "cuda"
     pending = []                                       # (slot in per_variant, ticket, input kept alive, (b, t))
@@ -233,10 +257,7 @@ def extract_features(backbone: Callable[[torch.Tensor], torch.Tensor], variants_
             per_variant.append(None)
         else:
             per_variant.append(backbone(x).flatten(1).view(b, t, -1).to(torch.float32))
-    for slot, ticket, _x, (b, t) in pending:
-        per_variant[slot] = ticket.wait().view(b, t, -1)
-    per_variant = [per_variant[0].flip(1) if isinstance(v, str) else v for v in per_variant]
-    return torch.stack(per_variant, dim=1)
+    return PendingFeatures(per_variant, pending)
 
 
 def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.RankContext] = None,
@@ -326,6 +347,19 @@ def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.Ran
     exchange = D.RoundExchange(ctx, layout, device, pack_round, host_slots=host_slots)
     my_batches = (D.n_batches(n_clips, bs) - ctx.rank + ctx.world - 1) // ctx.world if n_clips else 0
     n_rounds = D.n_rounds(n_clips, bs, ctx.world)
+    # One round AHEAD: round q's forward passes are submitted (backbone lanes: queued on their own streams) before round q - 1's features are
+    # waited for and posted, so that two batches are in flight on the device even without --augment.  The exchange sees the same sequence
+    # as before -- post(0), post(1), collect(0), post(2), collect(1), ... -- only one submission later.
+    held = None                                            # (features: tensor | PendingFeatures | None, variants_batch, box_batch) of round q - 1
+
+    def finish_round(qp: int) -> None:
+        feats, vb, bb_ = held
+        if isinstance(feats, PendingFeatures):
+            feats = feats.result()
+        exchange.post(qp, feats, vb, bb_)
+        if qp > 0:
+            exchange.collect(qp - 1)
+
     for q in range(n_rounds):
         feats = variants_batch = box_batch = None
         if q < my_batches:
@@ -340,13 +374,14 @@ def run_extraction(ds, args, backbone, device: torch.device, ctx: Optional[D.Ran
                     video, j3d, j2d, k, box = batch
                     variants_batch, box_batch = [(video, j3d, j2d, k)], box
                 t = variants_batch[0][0].shape[1]
-                feats = extract_features(backbone, variants_batch, device, reuse_trev=not getattr(args, "no_trev_reuse", False))
+                feats = submit_features(backbone, variants_batch, device, reuse_trev=not getattr(args, "no_trev_reuse", False))
             if t != args.seq_len:
                 raise RuntimeError(f"clips have {t} frames, --seq-len says {args.seq_len}")
-        exchange.post(q, feats, variants_batch, box_batch)
         if q > 0:
-            exchange.collect(q - 1)
+            finish_round(q - 1)
+        held = (feats, variants_batch, box_batch)
     if n_rounds > 0:
+        finish_round(n_rounds - 1)
         exchange.collect(n_rounds - 1)
     if stats is not None:
         stats["compute_done_s"] = time.time() - t_all
@@ -398,11 +433,11 @@ def main(argv: Optional[List[str]] = None) -> None:
     if args.synthetic_weights:
         log("WARNING    : --synthetic-weights: the backbone is a RANDOM-initialised ResNet-50; the shards will NOT hold ImageNet features")
     n_lanes = max(1, int(getattr(args, "lanes", 1)))
-    if n_lanes > 1 and args.augment and not args.device_producer:
+    if n_lanes > 1 and not args.device_producer:
         from .backbone import BackboneLanes
         backbone = BackboneLanes(lanes=n_lanes, state_dict=state_dict, max_batch=args.max_batch, micro_batch=args.micro_batch,
                                  precision=args.precision).to(device).eval()
-        log(f"Lanes      : {n_lanes} backbone copies on their own streams (the variants of a batch run {n_lanes} at a time)")
+        log(f"Lanes      : {n_lanes} backbone copies on their own streams (forward passes of a batch's variants / of consecutive batches run {n_lanes} at a time)")
     else:
         n_lanes = 1
         backbone = ResNet50Backbone(state_dict=state_dict, max_batch=args.max_batch, micro_batch=args.micro_batch,

@@ -72,6 +72,24 @@ def test_cli_augment_lanes_give_identical_files(tmp_path, lib_built):
             assert torch.equal(sa[key], sb[key]), (sid, key)
 
 
+def test_cli_lanes_without_augment_give_identical_files(tmp_path, lib_built):
+    """Without --augment a batch is ONE forward pass: run_extraction submits round q + 1 before it waits for round q, so consecutive batches
+    share the two lanes.  Seven clips in batches of two (four rounds, a ragged last one): the shards equal the one-lane run's."""
+    from implementation_phd_lab_vision_amd.preprocess_resnet_features import main
+    common = ["--root", "unused", "--synthetic-clips", "7", "--seq-len", "3", "--batch-size", "2", "--num-workers", "0",
+              "--shard-size", "3", "--shuffle-pool", "4", "--shuffle-seed", "5", "--device", "cuda", "--max-batch", "16", "--synthetic-weights"]
+    a, b = tmp_path / "lanes2", tmp_path / "lanes1"
+    main(common + ["--out", str(a)])
+    main(common + ["--out", str(b), "--lanes", "1"])
+    ia, ib = torch.load(a / "index.pt", weights_only=True), torch.load(b / "index.pt", weights_only=True)
+    assert ia["n_variants"] == 1 and ia["clips"] == ib["clips"] and ia["n_shards"] == ib["n_shards"] and ia["n_clips"] == 7
+    for sid in range(ia["n_shards"]):
+        sa = torch.load(a / f"shard_{sid:05d}.pt", weights_only=True)
+        sb = torch.load(b / f"shard_{sid:05d}.pt", weights_only=True)
+        for key in ("feats", "joints3d", "joints2d", "K"):
+            assert torch.equal(sa[key], sb[key]), (sid, key)
+
+
 def test_cli_with_a_checkpoint_file(tmp_path, lib_built):
     """--weights PATH: a torchvision-layout checkpoint (with fc.*, num_batches_tracked, a `module.` prefix) written to disk
     gives the same shards as the same weights handed over in memory, and its provenance is recorded beside the shards."""
