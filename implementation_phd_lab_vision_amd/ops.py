@@ -31,6 +31,8 @@ WS = 64                  # role-specialised kernel (4 loader waves + 4 or 8 cons
                          # WS|1 = 128x128 (4), WS|3 = 256x128 (8), WS|4 = 128x224 (4), WS|8 = 128x224 (8), WS|9 = 64x224 (4), WS|10 = 128x208 (4)
 TILE_XRES = 81           # 3x3 s1 p1 with Cin = Cout on 28x28 (128), 14x14 (256), 7x7 (512): input resident in LDS, only the weights stream (the automatic choice for these shapes)
 TILE_S2 = 82             # 3x3 STRIDE 2 p1 with Cin = Cout, 56 -> 28 (128) and 28 -> 14 (256): input resident by polyphase planes (the automatic choice for these shapes)
+TILE_G8 = 83              # 1x1, pad 0, Cout % 256 == 0: 256 couts x 256 pixels on the eight-phase schedule (gemm8p_kernel); also for conv1x1_cat
+TILE_G8_224 = 84          # the same with 224 pixels per tile (14 x 16 divides the pixel counts 2^k * 49 of the network)
 TILE_C64 = 80            # 3x3 s1 p1 64 -> 64 on 56x56 only (layer1 conv2): filter bank resident in LDS, input staged once per tile
 PERSISTENT = 32          # + PERSISTENT: chip-sized grid, tiles streamed through the LDS ring
 

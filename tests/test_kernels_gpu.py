@@ -65,10 +65,16 @@ CONV_CASES = [
     (2, 28, 28, 256, 256, 3, 2, 1, True, False),
     (1, 28, 28, 256, 256, 3, 2, 1, False, False),
     (5, 14, 14, 512, 512, 3, 2, 1, True, False),   # 14 -> 7: four images per tile (two pairs), the second tile holds one image
+    # eight-phase GEMM tiles (TILE_G8 / TILE_G8_224, 1x1): several pixel tiles with a ragged last one and two cout tiles, K = 512 (8 K-tiles)
+    # with a residual; K = 64 (ONE K-tile per tile: the stream's prologue, vmcnt(0) path); a strided source; 300 tiles on 256 CUs (tile stream)
+    (5, 14, 14, 512, 512, 1, 1, 0, True, True),
+    (3, 9, 9, 64, 256, 1, 1, 0, False, False),
+    (3, 12, 12, 256, 256, 1, 2, 0, True, False),
+    (75, 32, 32, 128, 256, 1, 1, 0, True, True),
 ]
 
 
-def _tiles_for(cout):
+def _tiles_for(cout, k=3, pad=1):
     from implementation_phd_lab_vision_amd import ops
     t = [ops.TILE_AUTO, ops.TILE_64x128, ops.TILE_64x256]
     if cout % 128 == 0:
@@ -80,6 +86,8 @@ def _tiles_for(cout):
         ws += [ops.WS | 1, ops.WS | 4, ops.WS | 8]
     if cout % 256 == 0:
         ws += [ops.WS | 3]
+    if cout % 256 == 0 and k == 1 and pad == 0:
+        ws += [ops.TILE_G8, ops.TILE_G8_224]
     return t + [x | ops.PERSISTENT for x in t if x != ops.TILE_AUTO] + ws
 
 
@@ -102,7 +110,9 @@ def test_conv2d_matches_oracle(lib_built, case):
     wd = wt.permute(0, 2, 3, 1).contiguous().to(d)
     bd = bias.to(d)
     rd = res.permute(0, 2, 3, 1).contiguous().to(d) if has_res else None
-    tiles = _tiles_for(cout)
+    tiles = _tiles_for(cout, k, pad)
+    if n >= 64:                      # the big case is there for the tile STREAM of the persistent kernels: the small tiles add nothing
+        tiles = [ops.TILE_AUTO, ops.TILE_256x256 | ops.PERSISTENT, ops.WS | 8, ops.TILE_G8, ops.TILE_G8_224]
     if (h, w, cin, cout, k, stride, pad, has_res) == (56, 56, 64, 64, 3, 1, 1, False):
         tiles = tiles + [ops.TILE_C64]
     if (k, stride, pad, has_res) == (3, 1, 1, False) and (h, w, cin, cout) in ((28, 28, 128, 128), (14, 14, 256, 256), (7, 7, 512, 512)):
@@ -117,6 +127,38 @@ def test_conv2d_matches_oracle(lib_built, case):
         torch.cuda.synchronize()
         _check_bf16(y, ref, f"conv tile={tile}")
         assert bool((buf[numel:] == -7.0).all()), f"conv tile={tile}: wrote past the end of the output"
+
+
+G8_SHAPES = [   # n, h (= w), cin, cout, residual: the streaming 1x1 convs of layer3 / layer4 at batch 256 (+ a batch that leaves the last tile ragged)
+    (256, 28, 512, 256, False), (256, 14, 1024, 256, False), (256, 14, 1024, 512, False), (256, 7, 2048, 512, False), (256, 7, 512, 2048, True),
+    (77, 7, 512, 2048, True), (50, 14, 1024, 512, False),
+]
+
+
+@pytest.mark.parametrize("et", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("shape", G8_SHAPES, ids=lambda v: "n%d_%dx%d_c%d-%d_res%d" % (v[0], v[1], v[1], v[2], v[3], v[4]))
+def test_gemm8p_tiles_give_the_bits_of_the_generic_tiles(lib_built, shape, et):
+    """gemm8p_kernel keeps igemm_bf16_kernel's K order per accumulator (bias first, K-tiles ascending, two 32-deep MFMAs per K-tile) and its
+    epilogue, so both of its tile widths must reproduce the two-stage 256x256 tile bit for bit -- at the sizes the network runs them at
+    (one to four rounds of tiles per workgroup through the stream of LDS-DMA stages: a stale or early fragment read shows up here),
+    three launches each, with a poisoned guard band behind the output."""
+    from implementation_phd_lab_vision_amd import ops
+    n, hw, cin, cout, has_res = shape
+    g = torch.Generator().manual_seed(n * 7 + cin)
+    d = _dev()
+    x = (torch.randn((n, hw, hw, cin), generator=g)).to(et).to(d)
+    wt = (torch.randn((cout, 1, 1, cin), generator=g) * (2.0 / cin) ** 0.5).to(et).to(d)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(d)
+    res = torch.randn((n, hw, hw, cout), generator=g).to(et).to(d) if has_res else None
+    ref = ops.conv2d_bf16(x, wt, bias, relu=True, residual=res, tile=ops.TILE_256x256)
+    numel = ref.numel()
+    for tile in (ops.TILE_G8, ops.TILE_G8_224):
+        for rep in range(3):
+            buf = torch.full((numel + 512 * cout,), -7.0, dtype=et, device=d)
+            y = ops.conv2d_bf16(x, wt, bias, relu=True, residual=res, tile=tile, out=buf)
+            torch.cuda.synchronize()
+            assert torch.equal(y, ref), f"tile {tile} rep {rep}: {int((y != ref).sum())} of {numel} elements differ"
+            assert bool((buf[numel:] == -7.0).all()), f"tile {tile}: wrote past the end of the output"
 
 
 @pytest.mark.parametrize("shape", [(5, 7, 512), (3, 28, 128), (3, 14, 256), (70, 14, 256), (300, 14, 256), (260, 7, 512)],
@@ -206,12 +248,38 @@ def test_bneck_block2_equals_unfused(lib_built, n, chain):
         assert y1n is None
 
 
+class _process_option:
+    """Sets a process-wide library option (through any handle) for the duration of a test."""
+    def __init__(self, key, value):
+        self.key, self.value = key, value
+
+    def __enter__(self):
+        from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
+        self.bb = ResNet50Backbone(seed=0, max_batch=2).to(_dev())
+        self.old = self.bb.get_option(self.key)
+        self.bb.set_option(self.key, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        self.bb.set_option(self.key, self.old)
+        self.bb.close()
+        return False
+
+
+@pytest.mark.parametrize("body1", [0, 7], ids=["ring_kernel", "body1_kernel"])
 @pytest.mark.parametrize("c1", [64, 128])
-@pytest.mark.parametrize("n", [1, 3, 20])
-def test_bneck_block1_equals_unfused(lib_built, n, c1):
+@pytest.mark.parametrize("n", [1, 3, 20, 41])
+def test_bneck_block1_equals_unfused(lib_built, n, c1, body1):
     """Layer1 bottleneck body in one launch: block output and next t1 are the same bits as the resident-weights 3x3 launch followed by
-    the 1x1 igemm launches (n = 20: 280 tiles, more than one per workgroup)."""
+    the 1x1 igemm launches (n = 20: 280 tiles, more than one per workgroup; n = 41: 574 tiles, up to three per workgroup: the register-staged
+    band / identity prefetch of bneck_body1_kernel runs two tiles ahead).  body1 = 7: bneck_body1_kernel (weights and identity through
+    registers, six barriers per tile) instead of bneck_block1_kernel (weight-stage ring)."""
     from implementation_phd_lab_vision_amd import ops
+    with _process_option("body1", body1):
+        _block1_case(ops, n, c1)
+
+
+def _block1_case(ops, n, c1):
     g = torch.Generator().manual_seed(5100 + n + c1)
     d = _dev()
     t1 = _rand_bf16((n, 56, 56, 64), g).clamp_(min=0).to(d)
@@ -231,12 +299,18 @@ def test_bneck_block1_equals_unfused(lib_built, n, c1):
     assert torch.equal(y1n, y1_ref), f"next conv1 differs: max |diff| {float((y1n.float() - y1_ref.float()).abs().max())}"
 
 
-@pytest.mark.parametrize("n", [1, 3, 20])
-def test_bneck_block1_downsample_equals_unfused(lib_built, n):
-    """layer1.0's body in one launch (bneck_block1_kernel<.., DS>): the identity is the downsample conv of the block input, computed in the
-    kernel and rounded to bf16 as the separate launch stores it.  Block output and next t1 are the same bits as the resident-weights 3x3 launch,
-    the 1x1 downsample launch, the 1x1 conv3 launch with that identity, and the next 1x1 launch."""
+@pytest.mark.parametrize("body1", [0, 7], ids=["ring_kernel", "body1_kernel"])
+@pytest.mark.parametrize("n", [1, 3, 20, 41])
+def test_bneck_block1_downsample_equals_unfused(lib_built, n, body1):
+    """layer1.0's body in one launch (bneck_block1_kernel<.., DS> / bneck_body1_kernel<.., DS>): the identity is the downsample conv of the block
+    input, computed in the kernel and rounded to bf16 as the separate launch stores it.  Block output and next t1 are the same bits as the
+    resident-weights 3x3 launch, the 1x1 downsample launch, the 1x1 conv3 launch with that identity, and the next 1x1 launch."""
     from implementation_phd_lab_vision_amd import ops
+    with _process_option("body1", body1):
+        _block1_ds_case(ops, n)
+
+
+def _block1_ds_case(ops, n):
     g = torch.Generator().manual_seed(5300 + n)
     d = _dev()
     t1 = _rand_bf16((n, 56, 56, 64), g).clamp_(min=0).to(d)
@@ -482,7 +556,9 @@ def test_conv2d_fp16_matches_oracle(lib_built, case):
     wd = wt.permute(0, 2, 3, 1).contiguous().to(d)
     bd = bias.to(d)
     rd = res.permute(0, 2, 3, 1).contiguous().to(d) if has_res else None
-    tiles = _tiles_for(cout)
+    tiles = _tiles_for(cout, k, pad)
+    if n >= 64:                      # the big case is there for the tile STREAM of the persistent kernels: the small tiles add nothing
+        tiles = [ops.TILE_AUTO, ops.TILE_256x256 | ops.PERSISTENT, ops.WS | 8, ops.TILE_G8, ops.TILE_G8_224]
     if (h, w, cin, cout, k, stride, pad, has_res) == (56, 56, 64, 64, 3, 1, 1, False):
         tiles = tiles + [ops.TILE_C64]
     for tile in tiles:
@@ -577,6 +653,10 @@ CAT_CASES = [   # n, h (= w) of the output, c1, h2 (= w2) of the second source, 
     (2, 6, 128, 11, 192, 2, 256, True, 64 | 1),    # 128x128 role-specialised tile, c2 not a power of two
     (2, 6, 128, 11, 192, 2, 256, True, 64 | 4),    # 128x224, 4 consumer waves
     (2, 6, 128, 11, 192, 2, 256, True, 64 | 3),    # 256x128
+    (2, 6, 128, 11, 192, 2, 256, True, 83),        # eight-phase GEMM tile (gemm8p_kernel, two K sources), one ragged tile
+    (9, 7, 256, 14, 512, 2, 1024, True, 83),       # layer3.0 family: M = 441 (two pixel tiles, the second ragged) x four cout tiles, K = 4 + 8 K-tiles
+    (9, 7, 256, 14, 512, 2, 1024, False, 84),      # the 224-pixel form
+    (6, 7, 512, 13, 1024, 2, 2048, True, 84),      # layer4.0 family, odd source size
 ]
 
 
