@@ -102,6 +102,56 @@ def cpu_baseline(sample_frames: int = 64, reps: int = 5, accuracy_of: dict = Non
     return out
 
 
+CLASS_LABELS = {
+    "igemm": "igemm_bf16_kernel + igemm_ws_kernel + gemm8p_kernel + conv3x3_xres_kernel + conv3x3_s2_kernel: every conv that is a launch of its own",
+    "bneck_block2": "bneck_block1_kernel (layer1.0 with its downsample conv, layer1.1, layer1.2) + bneck_block2_kernel (layer2.1-.3): a bottleneck body per launch",
+    "bneck_tail3": "bneck_tail3p_kernel: chained layer3 tails (conv3 + identity + ReLU + next conv1; layer3.5: conv3 alone)",
+    "bneck_catchain": "bneck_catchain_kernel: layer2.0 conv3 + downsample + ReLU chained with layer2.1.conv1",
+    "bneck_tail": "bneck_tail_kernel / bneck_tail2_kernel: fused layer1 / layer2 tails (not on the default path)",
+    "conv1": "stem_fused2_kernel: conv1 7x7 s2 + bn + ReLU + maxpool + layer1.0.conv1",
+    "avgpool": "avgpool_kernel",
+}
+TRAFFIC_KEYS = {"bneck_block2": "bneck_block"}       # class name in the committed PMC summary where it differs
+
+
+def roofline_object(prof: dict, steps: int, precision: str, traffic: dict = None, traffic_source: str = None) -> dict:
+    """The `roofline` object of the bench line from the library's per-class HIP-event profile (one lane, `steps` forwards).
+
+    The object describes the DOMINANT class = the one with the largest ms_per_step; `bound` is whichever of its two roofline fractions
+    is larger (these kernels stream and multiply at once, so both are given); every other class rides in `classes` with the same fields.
+    `achieved` = algorithmic flops (or layer-wise algorithmic bytes) of the class's launches / their summed event durations."""
+    mfma_peak = MFMA_FP8_PEAK_TFLOPS if precision == "fp8" else MFMA_BF16_PEAK_TFLOPS
+    traffic = traffic or {}
+
+    def describe(name: str, p: dict) -> dict:
+        sec = p["ms"] * 1e-3
+        tf = p["flops"] / sec / 1e12
+        gb = p["bytes"] / sec / 1e9
+        f_m, f_h = tf / mfma_peak, gb / HBM_PEAK_GBPS
+        by_mfma = f_m >= f_h
+        launches = max(1, p["launches"])
+        t = (traffic.get(TRAFFIC_KEYS.get(name, name)) or {}).get("hbm_bytes_per_launch")
+        d = {"class": name, "kernel": CLASS_LABELS.get(name, name), "bound": "mfma" if by_mfma else "hbm",
+             "achieved": tf if by_mfma else gb, "peak": mfma_peak if by_mfma else HBM_PEAK_GBPS, "unit": "TFLOP/s" if by_mfma else "GB/s",
+             "frac": f_m if by_mfma else f_h, "traffic": t, "traffic_source": traffic_source if t is not None else None,
+             "tflops": tf, "frac_of_mfma_peak": f_m, "GBps": gb, "frac_of_hbm_peak": f_h,
+             "launches_per_step": round(p["launches"] / max(1, steps)), "ms_per_step": p["ms"] / max(1, steps),
+             "avg_launch_us": 1e3 * p["ms"] / launches, "flops_per_launch": p["flops"] / launches, "algorithmic_bytes": p["bytes"] / launches,
+             "traffic_over_algorithmic": (t / (p["bytes"] / launches)) if (t and p["bytes"]) else None}
+        return d
+
+    live = {k: v for k, v in prof.items() if k in CLASS_LABELS and v.get("launches") and v.get("ms", 0) > 0}
+    if not live:
+        return None
+    top = max(live, key=lambda k: live[k]["ms"])
+    out = describe(top, live[top])
+    out["classes"] = {k: describe(k, v) for k, v in live.items() if k != top}
+    out["measured_on"] = "lane 0 alone (one batch at a time), HIP events on the launch stream around every launch of a second pass over the same steps"
+    out["traffic_note"] = ("FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per full-batch launch, batch 256 (static: see traffic_source); "
+                           "algorithmic_bytes = layer-wise in + out (+ residual) bytes of the same launches, from this run")
+    return out
+
+
 def timed_steps(step, fence, steps: int, warmup: int, preheat_s: float, frames_per_step: int, sync_max=None):
     """W untimed warm-up steps, an untimed pre-heat of the same step lasting >= preheat_s (clocks / power at their
     steady state before the clock starts), then EXACTLY `steps` timed steps between two fences.
@@ -145,8 +195,10 @@ def secondary_mode(precision: str, batch: int, steps: int, warmup: int, preheat_
         bb = ResNet50Backbone(state_dict=sd, max_batch=batch, precision=precision).to(dev).eval()
     try:
         x = synthetic_frames(batch, seed=1234).to(dev)
+        lanes_mode = "one lane"
         if lanes is not None:
-            lanes.tune(x, min_gain=1.01)
+            lanes.tune(x, min_gain=1.01)   # falls back to ONE lane when the lanes cost time (fp8 at batch 512: launches that leave no tail to fill)
+            n_lanes, lanes_mode = lanes.active_lanes, lanes.tune_mode
         feats_l = [torch.empty((batch, 2048), dtype=torch.float32, device=dev) for _ in range(max(1, n_lanes))]
         feats = feats_l[0]
         state = {"k": 0}
@@ -165,9 +217,13 @@ def secondary_mode(precision: str, batch: int, steps: int, warmup: int, preheat_
         lanes_equal = all(bool(torch.equal(feats_l[0], f)) for f in feats_l[1:]) if lanes is not None else None
         single = None
         if lanes is not None:
+            fell_back = lanes.active_lanes == 1
             lanes, lanes_obj = None, lanes        # from here on: lane 0 alone (the single-lane figure, the batch-2 check, the event profile)
-            el1, _ = timed_steps(step, fence, steps, 1, min(preheat_s, 0.3), batch)
-            single = {"value": batch * steps / el1, "unit": "frames/s", "ms_per_step": 1e3 * el1 / steps}
+            if fell_back:                         # the timed region above already ran one batch at a time: it IS the single-lane figure
+                single = {"value": batch * steps / elapsed, "unit": "frames/s", "ms_per_step": 1e3 * elapsed / steps, "note": "same measurement as `value` (one lane)"}
+            else:
+                el1, _ = timed_steps(step, fence, steps, 1, min(preheat_s, 0.3), batch)
+                single = {"value": batch * steps / el1, "unit": "frames/s", "ms_per_step": 1e3 * el1 / steps}
         if not bool(torch.isfinite(feats).all()):
             raise SystemExit(f"bench.py: non-finite features in the {precision} secondary run")
         small = bb.features(x[:2].contiguous())
@@ -183,10 +239,12 @@ def secondary_mode(precision: str, batch: int, steps: int, warmup: int, preheat_
         peak = MFMA_FP8_PEAK_TFLOPS if precision == "fp8" else MFMA_BF16_PEAK_TFLOPS
         # fp8 mode: layer1's three 3x3 convs run in 16 bits inside the same class; their flops are priced at the fp8 peak too (conservative)
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-        out = {"secondary": True, "precision": precision, "batch": batch, "steps": steps, "lanes": max(1, n_lanes), "single_lane": single,
+        out = {"secondary": True, "precision": precision, "batch": batch, "steps": steps, "lanes": max(1, n_lanes), "lanes_mode": lanes_mode,
+               "single_lane": single,
                "lanes_equal": lanes_equal, "value": batch * steps / elapsed,
                "unit": "frames/s", "ms_per_step": 1e3 * elapsed / steps, "preheat_frames_per_s": pre,
                "tflops": batch * steps / elapsed * GFLOP_PER_FRAME / 1e3,
+               "frac_of_peak_whole_step": batch * steps / elapsed * GFLOP_PER_FRAME / 1e3 / peak,
                "igemm": {"achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
                          "launches_per_step": ig["launches"] / steps},
@@ -267,7 +325,8 @@ def main() -> None:
     dist = None
     # a process group exists for N > 1, and also for ONE rank started by torchrun (RANK / WORLD_SIZE in the environment): that run
     # executes the multi-rank code path -- RCCL init with device_id, the gather of device tensors, barrier + fence -- on a one-GPU box
-    in_group = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and os.environ.get("R50_SINGLE_RANK_GROUP", "1") != "0")
+    from implementation_phd_lab_vision_amd.distributed import single_rank_group_requested
+    in_group = world > 1 or single_rank_group_requested()          # one rank: only under a launcher that set RANK, WORLD_SIZE and MASTER_PORT
     if in_group:
         import torch.distributed as dist
         if rehearsal:
@@ -369,7 +428,8 @@ def main() -> None:
             if dist is not None:
                 gather_feats()
     elif lanes is not None:
-        lane_gain = lanes.tune(x)          # the lanes' streams really run side by side (changed if not); untimed, results unaffected
+        lane_gain = lanes.tune(x)          # the lanes' streams really run side by side (changed if not; ONE lane if they cost time); untimed, results unaffected
+        n_lanes = lanes.active_lanes
         lane_state = {"k": 0, "free": [None] * n_lanes}
 
         def step():
@@ -417,7 +477,7 @@ def main() -> None:
     single_lane = None
     if lanes is not None:
         torch.cuda.synchronize(dev)
-        lanes_agree = all(bool(torch.equal(feats_l[0], f)) for f in feats_l[1:])
+        lanes_agree = all(bool(torch.equal(feats_l[0], f)) for f in feats_l[1:n_lanes])
         if dist is None:                   # the same K steps strictly one after the other on lane 0 (no second batch in flight)
             def step1():
                 run(x, out=feats)
@@ -471,72 +531,19 @@ def main() -> None:
         prof = bb.profile_collect()
         bb.set_option("profile", 0)
         bb.set_option("streams", n_streams)
-        ig = prof["igemm"]
-        achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         # HBM bytes per launch from rocprofv3 PMC passes (scripts/pmc_bench.sh: FETCH_SIZE x2 + WRITE_SIZE, full-batch launches only).
-        # A PMC pass cannot run inside this process: the figure is a STATIC one from the committed profile of the same build on another
-        # box of the pool, and the line says so (`traffic_source`); `algorithmic_bytes` beside it is computed live from this run.
-        traffic = None
-        tpath = next((p for p in (ROOT / "profiles" / "r03_pmc_hbm_traffic.json", ROOT / "profiles" / "r02_pmc_hbm_traffic.json") if p.exists()), None)
+        # A PMC pass cannot run inside this process: the figures are STATIC ones from the committed profile of the same build on another
+        # box of the pool, and the line says so (`traffic_source`); `algorithmic_bytes` beside them is computed live from this run.
+        tpath = next((p for p in (ROOT / "profiles" / "r04_pmc_hbm_traffic.json", ROOT / "profiles" / "r03_pmc_hbm_traffic.json") if p.exists()), None)
         tdata = {}
         if tpath is not None:
             try:
                 tdata = json.loads(tpath.read_text())
-                traffic = tdata["igemm"]["hbm_bytes_per_launch"]
             except Exception:
-                traffic = None
-        traffic_source = (f"profiles/{tpath.name} (rocprofv3 --pmc passes of this build on ANOTHER box of the pool, static; not measured in this run)"
+                tdata = {}
+        traffic_source = (f"profiles/{tpath.name} (rocprofv3 --pmc passes on ANOTHER box of the pool, static; not measured in this run)"
                           if tpath is not None else None)
-        roofline = {"bound": "mfma", "kernel": "igemm_bf16_kernel + igemm_ws_kernel + conv3x3_xres_kernel + conv3x3_s2_kernel (%d conv launches/step: every conv that is a launch of its own)" % round(ig["launches"] / max(1, args.steps)), "achieved": achieved,
-                    "peak": (MFMA_FP8_PEAK_TFLOPS if args.precision == "fp8" else MFMA_BF16_PEAK_TFLOPS), "unit": "TFLOP/s",
-                    "frac": achieved / (MFMA_FP8_PEAK_TFLOPS if args.precision == "fp8" else MFMA_BF16_PEAK_TFLOPS),
-                    "traffic": traffic, "traffic_source": traffic_source,
-                    "algorithmic_bytes": ig["bytes"] / max(1, ig["launches"]),
-                    "traffic_over_algorithmic": (traffic / (ig["bytes"] / max(1, ig["launches"]))) if (traffic and ig["bytes"]) else None,
-                    "traffic_note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per full-batch launch, batch 256; algorithmic_bytes = "
-                                    "layer-wise in + out (+ residual) bytes of the same launches, from this run",
-                    "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
-                    "flops_per_launch": ig["flops"] / max(1, ig["launches"]),
-                    "layerwise_GBps": ig["bytes"] / (ig["ms"] * 1e-3) / 1e9 if ig["ms"] > 0 else 0.0}
-        tl = prof.get("bneck_tail")
-        if tl and tl["ms"] > 0:       # second kernel family by time: the fused bottleneck tails are HBM-bound
-            t_traffic = None
-            try:
-                t_traffic = tdata["bneck_tail"]["hbm_bytes_per_launch"]
-            except Exception:
-                pass
-            t_ach = tl["bytes"] / (tl["ms"] * 1e-3) / 1e9
-            roofline["second_kernel"] = {"kernel": "bneck_tail_kernel / bneck_tail2_kernel (%d launches/step)" % round(tl["launches"] / max(1, args.steps)),
-                                         "bound": "hbm", "achieved": t_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": t_ach / HBM_PEAK_GBPS,
-                                         "traffic": t_traffic, "traffic_source": traffic_source, "avg_launch_us": 1e3 * tl["ms"] / max(1, tl["launches"]),
-                                         "algorithmic_bytes": tl["bytes"] / max(1, tl["launches"])}
-        t3 = prof.get("bneck_tail3")
-        if t3 and t3["ms"] > 0:       # the chained layer3 tails (conv3 + identity + ReLU + next conv1): both MFMA work and HBM streaming
-            t3_traffic = (tdata.get("bneck_tail3") or {}).get("hbm_bytes_per_launch")
-            roofline["third_kernel"] = {"kernel": "bneck_tail3p_kernel (chained layer3 tail, two-group pipeline; %d launches/step)" % round(t3["launches"] / max(1, args.steps)),
-                                        "traffic": t3_traffic, "traffic_source": traffic_source, "algorithmic_bytes": t3["bytes"] / max(1, t3["launches"]),
-                                        "avg_launch_us": 1e3 * t3["ms"] / max(1, t3["launches"]),
-                                        "tflops": t3["flops"] / (t3["ms"] * 1e-3) / 1e12, "frac_of_mfma_peak": t3["flops"] / (t3["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                                        "GBps": t3["bytes"] / (t3["ms"] * 1e-3) / 1e9, "frac_of_hbm_peak": t3["bytes"] / (t3["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-        cc = prof.get("bneck_catchain")
-        if cc and cc["ms"] > 0:       # layer2.0's transition tail (conv3 + downsample as one two-source conv) chained with layer2.1.conv1
-            roofline["fifth_kernel"] = {"kernel": "bneck_catchain_kernel (layer2.0 conv3 + downsample + ReLU chained with layer2.1.conv1; %d launches/step)" % round(cc["launches"] / max(1, args.steps)),
-                                        "traffic": (tdata.get("bneck_catchain") or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_source,
-                                        "algorithmic_bytes": cc["bytes"] / max(1, cc["launches"]), "avg_launch_us": 1e3 * cc["ms"] / max(1, cc["launches"]),
-                                        "tflops": cc["flops"] / (cc["ms"] * 1e-3) / 1e12, "frac_of_mfma_peak": cc["flops"] / (cc["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                                        "GBps": cc["bytes"] / (cc["ms"] * 1e-3) / 1e9, "frac_of_hbm_peak": cc["bytes"] / (cc["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-        b2 = prof.get("bneck_block2")
-        if b2 and b2["ms"] > 0:       # layer2.1-.3 bottleneck bodies in one launch each: MFMA work and HBM streaming at once
-            b_traffic = None
-            try:
-                b_traffic = tdata["bneck_block"]["hbm_bytes_per_launch"]
-            except Exception:
-                pass
-            roofline["fourth_kernel"] = {"kernel": "bneck_block1_kernel / bneck_block2_kernel (%d launches/step: layer1.1-.2, layer2.1-.3)" % round(b2["launches"] / max(1, args.steps)),
-                                         "traffic": b_traffic, "traffic_source": traffic_source, "algorithmic_bytes": b2["bytes"] / max(1, b2["launches"]),
-                                         "avg_launch_us": 1e3 * b2["ms"] / max(1, b2["launches"]),
-                                         "tflops": b2["flops"] / (b2["ms"] * 1e-3) / 1e12, "frac_of_mfma_peak": b2["flops"] / (b2["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                                         "GBps": b2["bytes"] / (b2["ms"] * 1e-3) / 1e9, "frac_of_hbm_peak": b2["bytes"] / (b2["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        roofline = roofline_object(prof, args.steps, args.precision, tdata, traffic_source)
         if args.dump_layers:          # launches of one forward in launch order: stem, the bottleneck launches, avgpool
             order = ([k for k in ("stem_pack", "conv1", "maxpool") if k in prof and prof[k]["launches"]]
                      + [k for k in prof if k.startswith("layer") and prof[k]["launches"]] + ["avgpool"])
@@ -591,12 +598,17 @@ def main() -> None:
                                    f"(BASELINE configs[{4 if args.precision == 'fp8' else 1}]), seeded synthetic weights, (N,2048) fp32 features"
                                    + (", RCCL gather to rank 0" if dist_used else ""),
                        "batch_per_gpu": args.batch, "micro_batch": args.micro_batch,
-                       "lanes": n_lanes, "lanes_tune": (getattr(lanes, "tune_log", None) if lanes is not None else None), "lanes_note": (f"{n_lanes} independent batches in flight, each on its own backbone copy + HIP stream (steps dealt round robin; "
+                       "lanes": n_lanes, "lanes_requested": max(1, args.lanes), "lanes_mode": (lanes.tune_mode if lanes is not None else "one lane"),
+                       "lanes_tune": (getattr(lanes, "tune_log", None) if lanes is not None else None), "lanes_note": (f"{n_lanes} independent batches in flight, each on its own backbone copy + HIP stream (steps dealt round robin; "
                                                         "every step is a whole batch-%d forward; nothing is shared or skipped)" % args.batch) if n_lanes > 1 else "one batch at a time",
                        "input": args.input + (" from pinned host memory every step (PCIe-inclusive, H2D overlapped)" if args.from_host else ""),
                        "parallelism": f"frames sharded over {world} rank(s)"},
+            # `value` is measured in this execution mode; `single_lane` (same run) is the strictly-one-batch-at-a-time figure, and `roofline` /
+            # `kernels` are measured on lane 0 alone (with two batches in flight a launch's duration is not its own)
+            "mode": (f"{n_lanes} batches in flight (BackboneLanes)" if n_lanes > 1 else "one batch at a time"),
             "tflops": value * GFLOP_PER_FRAME / 1e3,
             "frac_of_mfma_peak_whole_step": value * GFLOP_PER_FRAME / 1e3 / MFMA_BF16_PEAK_TFLOPS / world,
+            "frac_of_mfma_peak_whole_step_single_lane": (single_lane["value"] * GFLOP_PER_FRAME / 1e3 / MFMA_BF16_PEAK_TFLOPS) if single_lane else None,
             "preheat": {"seconds": args.preheat, "frames_per_s": preheat_rate},
             "checked": checked, "single_lane": single_lane,
             # the tolerance statement of the HEADLINE mode: bf16 is the reference's own GPU dtype (torch.autocast(bfloat16),

@@ -91,6 +91,15 @@ class ResNet50Backbone:
             if self._micro_batch:
                 self.set_option("micro_batch", self._micro_batch)
             return self
+        self._load_weights()
+        if self._micro_batch:
+            self.set_option("micro_batch", self._micro_batch)
+        if self._precision == PREC_FP8:
+            self.calibrate_fp8()
+        return self
+
+    def _load_weights(self) -> None:
+        """``r50_load_weights`` of this backbone's state dict into its handle (refused with R50_ERR_STATE once the handle shares weight buffers)."""
         named = list(iter_named_tensors(self._sd))
         descs = (_lib.TensorDesc * len(named))()
         keep = []
@@ -99,12 +108,7 @@ class ResNet50Backbone:
             descs[i].name = name.encode()
             descs[i].data = C.cast(t.data_ptr(), C.POINTER(C.c_float))
             descs[i].numel = t.numel()
-        _lib.check(lib.r50_load_weights(self._handle, descs, len(named)), self._handle, "r50_load_weights")
-        if self._micro_batch:
-            self.set_option("micro_batch", self._micro_batch)
-        if self._precision == PREC_FP8:
-            self.calibrate_fp8()
-        return self
+        _lib.check(_lib.load_library().r50_load_weights(self._handle, descs, len(named)), self._handle, "r50_load_weights")
 
     # ---- fp8 mode: activation scales ----------------------------------------------------------
     def set_fp8_scales(self, scales) -> None:
@@ -320,6 +324,9 @@ class BackboneLanes:
         self._bbs = [ResNet50Backbone(state_dict=sd, **backbone_kwargs) for _ in range(lanes)]
         self._streams = []
         self._next = 0
+        self._active = lanes              # lanes `submit` deals batches over (tune() may fall back to 1)
+        self.tune_log = []
+        self.tune_mode = f"{lanes} lanes (not tuned)" if lanes > 1 else "one lane"
         self._device: Optional[torch.device] = None
         self.training = False
 
@@ -379,16 +386,45 @@ class BackboneLanes:
             streams.append(cand)
         return streams
 
-    def tune(self, x: torch.Tensor, steps: int = 8, tries: int = 4, min_gain: float = 1.02) -> float:
+    @staticmethod
+    def lane_plan(ratios, n_lanes: int, min_gain: float = 1.02, drop_below: float = 1.0):
+        """What ``tune`` does with the ratios it measured (all lanes / one lane, one entry per try): ``(lanes to use, mode label)``.
+        The last ratio decides: at or above ``min_gain`` the lanes run side by side; below ``drop_below`` they make the step SLOWER
+        (big launches that leave no tail to fill: fp8 at batch 512 measured 0.97) and ``submit`` falls back to one lane; in between all
+        lanes stay (no loss, the streams just did not overlap much)."""
+        if n_lanes < 2:
+            return 1, "one lane"
+        if not ratios:
+            return n_lanes, f"{n_lanes} lanes (not tuned)"
+        r = ratios[-1]
+        if r < drop_below:
+            return 1, f"one lane (fallback: {n_lanes} lanes measured {r:.3f} x one lane)"
+        return n_lanes, f"{n_lanes} lanes ({r:.3f} x one lane{'' if r >= min_gain else ', below the tuning target'})"
+
+    @property
+    def active_lanes(self) -> int:
+        """Lanes ``submit`` deals batches over: all of them, or 1 after ``tune`` found that they do not pay for this workload."""
+        return self._active
+
+    def tune(self, x: torch.Tensor, steps: int = 8, tries: int = 4, min_gain: float = 1.02, drop_below: float = 1.0,
+             min_frames: int = 32) -> float:
         """Check with the REAL workload that the lanes run side by side, and change streams if they do not.  The spin-kernel check of
         ``_pick_streams`` is necessary but was seen not to be sufficient (one bench.py process in ~10 still showed two lanes = one lane:
         how the firmware maps the runtime's queues onto the hardware is not ours to see).  ``steps`` forwards of ``x`` on lane 0 alone against
         ``steps`` forwards dealt over the lanes; below ``min_gain`` the lanes behind the first get new streams (again checked with the spin
-        kernels) and the measurement is repeated, ``tries`` times at most.  Returns the last ratio measured (two lanes / one).  Costs
-        ~2 x steps forwards per try; never affects results."""
+        kernels) and the measurement is repeated, ``tries`` times at most.  If the last ratio is below ``drop_below`` the lanes cost more
+        than they give for this workload and ``submit`` uses lane 0 only from here on (``active_lanes``, ``tune_mode``).  A batch of fewer than
+        ``min_frames`` frames is too short to measure (the ratio would be launch noise): nothing is measured or changed.  Returns the last
+        ratio measured (all lanes / one); the ratios are informational (``tune_log``) -- results never depend on them.  Costs ~2 x steps
+        forwards per try."""
         import time
         if len(self._bbs) < 2:
             return 1.0
+        if x.shape[0] < min_frames:
+            self.tune_log = []
+            self.tune_mode = f"{len(self._bbs)} lanes (not tuned: {x.shape[0]} frames are too few to measure)"
+            return 1.0
+        self._active = len(self._bbs)
         dev = self._device
         outs = [torch.empty((x.shape[0], FEATURE_DIM), dtype=torch.float32, device=dev) for _ in self._bbs]
 
@@ -425,6 +461,7 @@ class BackboneLanes:
                     new.append(cand)
                 self._streams = new
         self._next = 0
+        self._active, self.tune_mode = self.lane_plan(self.tune_log, len(self._bbs), min_gain, drop_below)
         return ratio
 
     def cuda(self, device=None) -> "BackboneLanes":
@@ -476,19 +513,21 @@ class BackboneLanes:
         caller guarantees both are ready (static inputs).  The lane's previous batch is ordered before this one by its stream.
         The caller keeps ``x`` and ``out`` alive until ``ticket.event`` has fired (``ticket.wait()``), and allocates ``out`` itself
         when it is given: a tensor made here is allocated on the CURRENT stream and first written on the lane's, so when ``out`` is
-        None an ``after`` event is recorded on the current stream if none was passed."""
+        None the lane additionally waits for an event recorded on the current stream right behind the allocation (whatever ``after`` says)."""
         if self._device is None:
             raise _lib.R50Error("call .to('cuda:N') before running the backbone")
-        lane = self._next
-        self._next = (lane + 1) % len(self._bbs)
+        lane = self._next % self._active
+        self._next = (lane + 1) % self._active
         bb, st = self._bbs[lane], self._streams[lane]
-        if out is None:
-            out = torch.empty((x.shape[0], FEATURE_DIM), dtype=torch.float32, device=self._device)
-            if after is None:
-                after = torch.cuda.Event()
-                after.record(torch.cuda.current_stream(self._device))
         if after is not None:
             st.wait_event(after)
+        if out is None:
+            # allocated on the CURRENT stream: the caching allocator may hand out a block whose last use on that stream was queued AFTER the
+            # caller's `after` event was recorded, so the lane also waits for everything queued on the current stream up to this point
+            out = torch.empty((x.shape[0], FEATURE_DIM), dtype=torch.float32, device=self._device)
+            fresh = torch.cuda.Event()
+            fresh.record(torch.cuda.current_stream(self._device))
+            st.wait_event(fresh)
         # allocator bookkeeping: both tensors are used on the lane's stream, whichever stream they were allocated on (e.g. a prefetcher's copy
         # stream) -- their blocks must not be handed out again before the lane's kernels are done
         x.record_stream(st)

@@ -4379,7 +4379,6 @@ struct Block1Args {
     __bf16* y1n;          // (M, C1N)
     int N;
     int n_tiles;          // 14 N
-    const __bf16* wp;     // bneck_body1_kernel only: the block's weights in MFMA fragment order (body1_pack_kernel)
 };
 
 template <int ET, int C1N, bool DS = false>
@@ -4683,333 +4682,6 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
         if (wave_q < 2) run(std::integral_constant<int, 4>{});
         else run(std::integral_constant<int, 3>{});
     }
-#else
-    (void)a;
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// bneck_body1_kernel (round 4): the layer1 bottleneck body of bneck_block1_kernel WITHOUT a weight-stage ring and without loader waves.
-// Why: bneck_block1_kernel's time is its barrier skeleton -- 17-21 stage barriers per 224-pixel tile, each one the end of the chain "a loader
-// issues an 8-KB stage -> it lands -> barrier -> the consumers' first fragment reads" (~1,430 cycles per stage for ~256 cycles of MFMA
-// issue), and its identity rows are requested ONE barrier interval (~0.7 us) before they are needed, less than an HBM round trip under load.
-// At 56x56 the block is bound by what a CU streams (1.3 KB of HBM traffic per pixel against 0.14 MFLOP: 27 k cycles of streaming per tile for
-// 7.6 k cycles of MFMA issue), so the kernel is built around keeping reads in flight:
-//   * EIGHT identical waves (wave_a = cout half: 32 of 64 rows, wave_q = pixel quarter: 4 + 4 + 3 + 3 MFMA column blocks), 256 registers each;
-//     no LDS-DMA anywhere, so hipcc's vmcnt bookkeeping of the plain loads below is exact;
-//   * WEIGHTS go L2 -> registers: body1_pack_kernel stores every [64 rows][64 K] weight stage of the block (9 conv2 taps, then per 64-channel
-//     chunk c of the block output W3[64 c ..], (DS) Wd[64 c ..], W1[.., 64 c ..]) in MFMA fragment order, [stage][wave_a][kk][m][lane][16 B],
-//     so a wave fetches a stage's four A fragments with four coalesced 1-KB loads, two stages ahead (three register sets); nothing about a
-//     weight stage passes through LDS and no barrier guards it;
-//   * the IDENTITY goes HBM -> registers in accumulator layout (a lane needs exactly the 16 B of its own 8 channels of its own pixel per
-//     block), requested TWO chunks (half a tile) ahead;
-//   * the t1 BAND with its halo (348 padded positions x 128 B), and for DS the tile's 224 block-input rows, go HBM -> registers one TILE
-//     ahead and are written to LDS with ds_write_b128 when their buffer falls free;
-//   * the block output's chunk passes through LDS (OUTC, double buffered: it is the B operand of the next conv1's K-slice) and is copied
-//     to HBM in full 128-B rows by all eight waves;
-//   * SIX barriers per tile: S0 (band of this tile in LDS), S1 (t2 complete, band dead), X(c) (OUTC(c) complete), c = 0..3.
-// Hand-overs: T2 / OUTC(c) written before S1 / X(c) (each wave's ds_writes retired by the lgkmcnt(0) in front of every barrier), read
-// behind it; OUTC[c & 1] is rewritten by E(c + 2) behind X(c + 1), which every wave passes after its B(c) reads and its share of the
-// copy-out of chunk c; the next tile's band is written behind S1 (every conv2 read of this tile is in front of it) and read behind the
-// next S0; XIN (DS) is rewritten behind X(3), read behind the next S0.
-// Same summation orders as bneck_block1_kernel (conv2: bias, taps ascending, K halves inside; conv3 / next conv1: bias first, K ascending,
-// identity last with the same fp32 additions; DS identity rounded to 16 bits first): bit-identical outputs.
-// LDS: XB 45,056 | T2 28,672 | OUTC 2 x 28,672 | (DS) XIN 28,672 | biases = 132,864 B (DS: 162,560 B).
-// ------------------------------------------------------------------------------------------------
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// one 16-byte piece per thread: stage s of the block's weight stream, fragment (wave_a, kk, m) of `lane` -> wp[(s * 512 + (wave_a * 4 + kk * 2 + m) * 64 + lane) * 8 ..]
-__global__ void body1_pack_kernel(const __bf16* __restrict__ w2, const __bf16* __restrict__ w3, const __bf16* __restrict__ wd,
-                                  const __bf16* __restrict__ w1, int c1n, __bf16* __restrict__ wp) {
-    const int ds = wd != nullptr ? 1 : 0, nb1 = c1n / 64, lch = 1 + ds + nb1, ns = 9 + 4 * lch;
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= ns * 512) return;
-    const int s = g >> 9, r = g & 511, wave_a = r >> 8, kk = (r >> 7) & 1, m = (r >> 6) & 1, lane = r & 63, fr = lane & 15, fq = lane >> 4;
-    const int rho = wave_a * 32 + 16 * m + fr;                       // LDS row of the stage in the ring kernels -> channel (permuted inside 32-row groups)
-    const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
-    const int ko = (fq + 4 * kk) * 8;
-    const __bf16* src;
-    if (s < 9) {
-        src = w2 + cl * 576 + s * 64 + ko;
-    } else {
-        const int q = s - 9, c = q / lch, rr = q - c * lch;
-        if (rr == 0) src = w3 + (64 * c + cl) * 64 + ko;
-        else if (ds && rr == 1) src = wd + (64 * c + cl) * 64 + ko;
-        else src = w1 + (64 * (rr - 1 - ds) + cl) * 256 + 64 * c + ko;
-    }
-    *reinterpret_cast<u32x4*>(wp + (size_t)g * 8) = *reinterpret_cast<const u32x4*>(src);
-}
-
-#ifndef B1N_ABL             // diagnostic ablations of bneck_body1_kernel (timing only, wrong results): 1 = no identity loads, 2 = no band loads, 4 = no copy-out stores, 8 = no weight loads
-#define B1N_ABL 0
-#endif
-template <int ET, int C1N, bool DS = false>
-__global__ __launch_bounds__(512) void bneck_body1_kernel(const Block1Args a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(C1N == 64 || C1N == 128, "next conv1: 256 -> 64 or 256 -> 128");
-    constexpr int IW = 56, TR = 4, PW = IW + 2, PP = (TR + 2) * PW;       // 348 padded positions
-    constexpr int XBUF = 11 * 32 * 128;                                   // 45,056 B (352 positions)
-    constexpr int NPX = TR * IW, SLOT = NPX * 128;                        // 224 rows, 28,672 B
-    constexpr int XB_OFF = 0, T2_OFF = XBUF, OUTC_OFF = T2_OFF + SLOT, XIN_OFF = OUTC_OFF + 2 * SLOT, BIAS_OFF = XIN_OFF + (DS ? SLOT : 0);
-    constexpr int NB1 = C1N / 64, NA = DS ? 2 : 1, LCH = NA + NB1;
-    // weight stages per tile, fetched WS - 1 stages ahead into WS register sets (DS / C1N = 128 carry a second accumulator set: two sets); the stage count is
-    // padded to the sets' period so that a stage's set is a compile-time constant in every tile
-    constexpr int WS = (DS || C1N == 128) ? 2 : 3, IDA = (C1N == 128) ? 1 : 2;     // IDA: chunks the identity loads run ahead
-    constexpr int NS = 9 + 4 * LCH, NSP = (NS + WS - 1) / WS * WS;
-    constexpr int BD_IDX = 64 + 256 + C1N;
-    constexpr int BAND_PIECES = PP * 8, BPASS = (BAND_PIECES + 511) / 512;  // 2,784 16-byte pieces: 6 passes of the 512 threads
-    constexpr int ROW_PIECES = NPX * 8, RPASS = (ROW_PIECES + 511) / 512;   // 1,792: 4 passes (the last one waves 0-3 only)
-    static_assert(BIAS_OFF + (448 + 256) * 4 <= 163840, "LDS map");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grid = gridDim.x, first = blockIdx.x;
-#define B1_BAR() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-
-    if (tid < 64 + 256 + C1N) {
-        float v;
-        if (tid < 64) v = a.b2[tid];
-        else if (tid < 320) v = a.b3[tid - 64];
-        else v = a.b1[tid - 320];
-        reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = v;
-    }
-    if (DS && tid < 256) reinterpret_cast<float*>(smem + BIAS_OFF)[BD_IDX + tid] = a.bd[tid];
-
-    const int wave_a = wave & 1, wave_q = wave >> 1;                     // cout group (32 of 64), pixel quarter: blocks 0-3, 4-7, 8-10, 11-13
-    const int qb0 = wave_q < 2 ? 4 * wave_q : 8 + 3 * (wave_q - 2);
-    const int fr = lane & 15, fq = lane >> 4;
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.t1), 0, (unsigned)a.N * (3136u * 128u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.N * (3136u * (DS ? 128u : 512u)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.N * (3136u * 512u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.N * (3136u * C1N * 2u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wp), 0, (unsigned)NS * 8192u, 0x00020000);
-    const int ch_lane = wave_a * 32 + 8 * fq;                        // this lane's 8 consecutive channels of a 64-channel group
-    // pixel row p = p0 + 16 j of block j: B fragment (kk = 0) at pb0 + 2048 j of a K-slot (p & 7 does not depend on j); kk = 1 is ^ 64;
-    // this lane's 8 channels of that row (as the B operand of the NEXT GEMM): (pb0 + 2048 j) ^ cf_x
-    const int p0 = 16 * qb0 + fr, pb0 = p0 * 128 + ((fq ^ (p0 & 7)) << 4), cf_x = wave_a << 6;
-    const unsigned wp_lane = (unsigned)(wave_a * 4096 + lane * 16);
-
-    auto tile_pix = [&](int tile) { const int n = tile / 14; return (unsigned)(n * 3136 + (tile - n * 14) * NPX); };
-    // ---- operand movers shared by all waves --------------------------------------------------------
-    u32x4 bandq[BPASS];                       // the NEXT tile's band, in flight / waiting for XB to fall free
-    auto band_load = [&](int tile) {
-        const int n = tile / 14, tr = tile - n * 14;
-#pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-            const int e = i * 512 + tid, q = e >> 3, slot = e & 7;
-            const int rr = q / PW, cc = q - rr * PW;
-            const int y = tr * TR + rr - 1, x = cc - 1;
-            const bool ok = e < BAND_PIECES && tile < a.n_tiles && (unsigned)y < 56u && (unsigned)x < 56u;
-            // chunk key of a position = (rr * IW + cc) & 7 (bneck_block1_kernel's: conflict-free fragment reads across row wraps)
-            const unsigned voff = ok ? (unsigned)(((n * 56 + y) * 56 + x) * 64 + (slot ^ ((rr * IW + cc) & 7)) * 8) * 2u : kOobOffset;
-            if (B1N_ABL & 2) bandq[i] = (u32x4){voff, 0u, 0u, 0u}; else
-            bandq[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff, 0, 0);
-        }
-    };
-    auto band_write = [&]() {
-#pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-            const int e = i * 512 + tid;
-            if (e < XBUF / 16) *reinterpret_cast<u32x4*>(smem + XB_OFF + e * 16) = bandq[i];
-        }
-    };
-    u32x4 xinq[DS ? RPASS : 1];               // DS: the next tile's 224 block-input rows (64 channels)
-    auto xin_load = [&](int tile) {
-        const unsigned pix = tile_pix(tile);
-#pragma unroll
-        for (int i = 0; i < (DS ? RPASS : 0); ++i) {
-            const int e = i * 512 + tid, R = e >> 3, sl = e & 7;
-            const unsigned voff = (e < ROW_PIECES && tile < a.n_tiles) ? ((pix + (unsigned)R) * 64u + (unsigned)((sl ^ (R & 7)) * 8)) * 2u : kOobOffset;
-            xinq[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff, 0, 0);
-        }
-    };
-    auto xin_write = [&]() {
-#pragma unroll
-        for (int i = 0; i < (DS ? RPASS : 0); ++i) {
-            const int e = i * 512 + tid;
-            if (e < ROW_PIECES) *reinterpret_cast<u32x4*>(smem + XIN_OFF + e * 16) = xinq[i];
-        }
-    };
-    auto copy_out = [&](unsigned pix, int c, int tid) {   // OUTC[c & 1] -> block output, full 128-B rows (8 lanes per row); `tid`: the caller's per-tile copy
-        const char* ob = smem + OUTC_OFF + (c & 1) * SLOT;
-        u32x4 v[RPASS];
-#pragma unroll
-        for (int i = 0; i < RPASS; ++i) {
-            const int e = i * 512 + tid;
-            if (e < ROW_PIECES) v[i] = *reinterpret_cast<const u32x4*>(ob + e * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < RPASS; ++i) {
-            const int e = i * 512 + tid, R = e >> 3, sl = e & 7;
-            if (e < ROW_PIECES)
-                if (!(B1N_ABL & 4) || v[i][0] == 0x12345678u)
-                __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, ((pix + (unsigned)R) * 256u + (unsigned)(c * 64 + (sl ^ (R & 7)) * 8)) * 2u, 0, 0);
-        }
-    };
-
-    auto run = [&](auto nq_c) {
-        constexpr int NQ = decltype(nq_c)::value;
-        f32x4 acc[2][NQ], accB[NB1][2][NQ], accD[2][DS ? NQ : 1];
-        u32x4 wq[WS][4];                      // weight stages in flight / in use: [set][kk * 2 + m]
-        u32x4 idq[4][DS ? 1 : NQ];            // identity of chunk c, this lane's 16 B per pixel block
-        auto wload = [&](auto set_c, int stage) {
-            constexpr int SET = decltype(set_c)::value;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                if (B1N_ABL & 8) wq[SET][f] = (u32x4){wp_lane + (unsigned)stage, 0x3f803f80u, 0x3f803f80u, (unsigned)f};
-                else wq[SET][f] = __builtin_amdgcn_raw_buffer_load_b128(rs_wp, wp_lane + (unsigned)(f * 1024), stage * 8192, 0);
-            }
-        };
-        auto id_load = [&](auto c_c, int tile, int p0) {
-            constexpr int C = decltype(c_c)::value;
-            if constexpr (!DS) {
-                const unsigned pix = tile_pix(tile) + (unsigned)p0;
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) {
-                    const unsigned voff = tile < a.n_tiles ? ((pix + 16u * j) * 256u + (unsigned)(C * 64 + ch_lane)) * 2u : kOobOffset;
-                    if (B1N_ABL & 1) idq[C][j] = (u32x4){voff, 0u, 0u, 0u}; else
-                    idq[C][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff, 0, 0);
-                }
-            }
-        };
-        // stage S of the tile's weight stream: fetch stage S + WS - 1 (into the set stage S - 1 has just left), then ac += W(S) . X
-        auto stage = [&](auto s_c, auto xaddr, auto& ac) {
-            constexpr int S = decltype(s_c)::value, S2 = S + WS - 1;
-            if constexpr (S2 < NS) wload(std::integral_constant<int, S2 % WS>{}, S2);
-            else if constexpr (S2 >= NSP) wload(std::integral_constant<int, S2 % WS>{}, S2 - NSP);  // the next tile's first stages (same weights)
-            if constexpr (S < NS) {
-                constexpr int SET = S % WS, NSX = 2 * NQ, PD = 3;
-                bf16x8 x[NSX];
-#pragma unroll
-                for (int t = 0; t < PD; ++t) x[t] = *reinterpret_cast<const bf16x8*>(xaddr(t));
-#pragma unroll
-                for (int t = 0; t < NSX; ++t) {
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        ac[m][t % NQ] = mfma_e<ET>(__builtin_bit_cast(bf16x8, wq[SET][(t >= NQ ? 2 : 0) + m]), x[t], ac[m][t % NQ]);
-                    if (t + PD < NSX) x[t + PD] = *reinterpret_cast<const bf16x8*>(xaddr(t + PD));
-                }
-                // the pixel fragments stay PD reads ahead of their MFMAs (hipcc would issue all 2 NQ reads first: 32 registers instead of 16)
-                __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
-#pragma unroll
-                for (int t = 0; t < NSX; ++t) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    if (t + PD < NSX) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);    // keeps hipcc from hoisting later stages' loads (into fresh registers) above this one
-        };
-        auto pack_relu = [&](const f32x4& lo, const f32x4& hi) {
-            u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
-            return o;
-        };
-        auto set_bias = [&](auto& ac, int fidx) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (fidx + ch_lane) * 4);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (fidx + ch_lane + 4) * 4);
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) { ac[0][j] = lo; ac[1][j] = hi; }
-        };
-
-        // ---- prologue: the first tile's band (and block-input rows) into LDS, the second tile's into registers; first weights / identities
-        static_for<0, WS - 1>([&](auto s_c) { wload(s_c, decltype(s_c)::value); });
-        static_for<0, IDA>([&](auto c_c) { id_load(c_c, first, p0); });
-        band_load(first);
-        band_write();
-        band_load(first + grid);
-        if constexpr (DS) { xin_load(first); xin_write(); xin_load(first + grid); }
-#pragma unroll 1
-        for (int tile = first; tile < a.n_tiles; tile += grid) {
-            const unsigned tpix = tile_pix(tile);
-            // an opaque zero per tile: the lane constants below (fragment / copy-out / identity addresses) are recomputed in every tile instead of being
-            // hoisted out of the tile loop, where the unrolled body's ~80 of them would live in registers next to the accumulators and prefetch sets
-            int opq = 0;
-            asm volatile("" : "+v"(opq));
-            const int tidq = tid + opq, p0q = p0 + opq, pb0q = pb0 + opq;
-            B1_BAR();                         // S0: this tile's band (and XIN) complete in LDS; biases too (first tile)
-            // ---- conv2: bias, nine taps against the resident band
-            set_bias(acc, 0);
-            {
-                int q0[NQ];
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) {
-                    const int p = p0q + 16 * j;
-                    const int r = p / IW, c = p - r * IW;
-                    q0[j] = r * PW + c;
-                }
-                static_for<0, 9>([&](auto tap_c) {
-                    constexpr int tap = decltype(tap_c)::value, kh = tap / 3, kw = tap - 3 * kh;
-                    const int sw = (kh * PW + kw) * 128 + ((fq ^ ((p0q + kh * IW + kw) & 7)) << 4);     // tap offset + the tap's chunk key
-                    stage(tap_c, [&](int t) { return smem + XB_OFF + q0[t % NQ] * 128 + (t >= NQ ? (sw ^ 64) : sw); }, acc);
-                });
-            }
-            // ---- t2 = relu(acc) -> T2
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) *reinterpret_cast<u32x4*>(smem + T2_OFF + ((pb0q + 2048 * j) ^ cf_x)) = pack_relu(acc[0][j], acc[1][j]);
-#pragma unroll
-            for (int h = 0; h < NB1; ++h) set_bias(accB[h], 320 + 64 * h);
-            B1_BAR();                         // S1: T2 complete; nobody reads the band any more
-            band_write();                     // the next tile's band takes its place ...
-            band_load(tile + 2 * grid);       // ... and the one after that starts its way
-            static_for<0, 4>([&](auto c_c) {
-                constexpr int c = decltype(c_c)::value, SA = 9 + c * LCH;
-                char* const oc = smem + OUTC_OFF + (c & 1) * SLOT;
-                set_bias(acc, 64 + 64 * c);
-                // ---- A(c): W3[64 c ..] . t2
-                stage(std::integral_constant<int, SA>{}, [&](int t) { return smem + T2_OFF + ((pb0q + 2048 * (t % NQ)) ^ (t >= NQ ? 64 : 0)); }, acc);
-                if constexpr (DS) {           // ---- the identity's chunk: Wd[64 c ..] . block input (the tile's rows, XIN) from bias bd
-                    set_bias(accD, BD_IDX + 64 * c);
-                    stage(std::integral_constant<int, SA + 1>{}, [&](int t) { return smem + XIN_OFF + ((pb0q + 2048 * (t % NQ)) ^ (t >= NQ ? 64 : 0)); }, accD);
-                }
-                // ---- E(c): + identity, ReLU, 16 bit -> OUTC[c & 1]: the block output's chunk and the next conv1's K-slice
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) {
-                    u32x4 rr;
-                    if constexpr (DS) rr = (u32x4){pack2_e<ET>(accD[0][j][0], accD[0][j][1]), pack2_e<ET>(accD[0][j][2], accD[0][j][3]),
-                                                   pack2_e<ET>(accD[1][j][0], accD[1][j][1]), pack2_e<ET>(accD[1][j][2], accD[1][j][3])};
-                    else rr = idq[c][j];
-                    f32x4 lo = acc[0][j], hi = acc[1][j];
-                    lo[0] += unpack_lo_e<ET>(rr[0]); lo[1] += unpack_hi_e<ET>(rr[0]);
-                    lo[2] += unpack_lo_e<ET>(rr[1]); lo[3] += unpack_hi_e<ET>(rr[1]);
-                    hi[0] += unpack_lo_e<ET>(rr[2]); hi[1] += unpack_hi_e<ET>(rr[2]);
-                    hi[2] += unpack_lo_e<ET>(rr[3]); hi[3] += unpack_hi_e<ET>(rr[3]);
-                    *reinterpret_cast<u32x4*>(oc + ((pb0q + 2048 * j) ^ cf_x)) = pack_relu(lo, hi);
-                    __builtin_amdgcn_sched_barrier(0);        // one pixel block at a time (12 temporaries each)
-                }
-                // the identity IDA chunks on (the next tile's for the last ones) starts its way now
-                __builtin_amdgcn_sched_barrier(0);
-                id_load(std::integral_constant<int, (c + IDA) & 3>{}, c + IDA < 4 ? tile : tile + grid, p0q);
-                B1_BAR();                     // X(c): OUTC[c & 1] complete
-                copy_out(tpix, c, tidq);
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- B(c): W1[64 h .., 64 c ..] . out_c into the next conv1's accumulators
-                static_for<0, NB1>([&](auto h_c) {
-                    constexpr int h = decltype(h_c)::value;
-                    stage(std::integral_constant<int, SA + NA + h>{}, [&](int t) { return oc + ((pb0q + 2048 * (t % NQ)) ^ (t >= NQ ? 64 : 0)); }, accB[h]);
-                });
-            });
-            static_for<NS, NSP>([&](auto s_c) { stage(s_c, [&](int) { return smem; }, acc); });      // padding stages: only their prefetch
-            const unsigned pix0 = tpix + (unsigned)p0q;
-#pragma unroll
-            for (int h = 0; h < NB1; ++h)
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) {
-                    const u32x4 o = pack_relu(accB[h][0][j], accB[h][1][j]);
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, ((pix0 + 16 * j) * (unsigned)C1N + (unsigned)(64 * h + ch_lane)) * 2u, 0, 0);
-                }
-            if constexpr (DS) { xin_write(); xin_load(tile + 2 * grid); }      // behind X(3): every D(3) read of XIN is done
-        }
-    };
-    if (wave_q < 2) run(std::integral_constant<int, 4>{});
-    else run(std::integral_constant<int, 3>{});
-#undef B1_BAR
 #else
     (void)a;
 #endif

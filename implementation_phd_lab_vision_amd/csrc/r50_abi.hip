@@ -74,7 +74,6 @@ struct r50_handle {
     __bf16* tail3_wp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per layer3 block b: [W3(b) | W1(b+1)] in the kernel's fragment order
     int fuse_block1 = 3;                // 1: layer1.1, 2 (default since round 3: with the loaders' position loop unrolled the c1 = 128 form takes 248 us against
                                         // 276 for conv2 + fused tail): also layer1.2 -- the bottleneck body in one launch (bneck_block1_kernel)
-    __bf16* body1_wp[3] = {nullptr, nullptr, nullptr};   // per layer1 block: its weights in bneck_body1_kernel's fragment-ordered stream (body1_pack_kernel)
     int fuse_block2 = 1;                // layer2.1-.3: the whole bottleneck body (conv2 + conv3 + identity + ReLU [+ next conv1]) in one launch
     int inplace_out = 0;                // plain-identity blocks write their output over their input (same bits, fewer DRAM page switches)
     int n_streams = 1;                  // > 1: the batch is split over internal streams (forked from / joined to the caller's)
@@ -594,11 +593,21 @@ int g_use_xres = [] { const char* v = std::getenv("R50_XRES"); return v ? std::a
 int g_use_s2 = [] { const char* v = std::getenv("R50_S2"); return v ? std::atoi(v) : 1; }();          // A/B knob: 0 = generic igemm tiles for the 3x3 s2 shapes
 // Eight-phase GEMM tiles for the streaming 1x1 convs: 0 = never, 1 = the shapes of kG8 (measured at batch 256), 2 / 3 = wherever the shape fits, 256 / 224 pixels
 // (A/B knob: R50_G8 / option "use_g8").
-int g_use_g8 = [] { const char* v = std::getenv("R50_G8"); return v ? std::atoi(v) : 0; }();
+int g_use_g8 = [] { const char* v = std::getenv("R50_G8"); return v ? std::atoi(v) : 1; }();
+// Where the eight-phase tiles beat the tuned generic ones at batch 256 (scripts/time_g8.py, profiles/r04_time_g8.txt; same-process medians):
+// layer3.1.conv1 32.3 against 33.9 us, layer4.0.conv1 56.8 against 60.0, the two-source conv3 + downsample GEMMs of layer3.0 / layer4.0 88.9 / 86.6
+// against 90.7 / 88.6 -- all with 224-pixel tiles (whole blocks of the pixel counts 2^k x 49; 256-pixel tiles leave 23 % of the last round empty).
+// NOT layer3.0.conv1 (HBM-bound, 3.5 rounds of 224-pixel tiles), layer4.x.conv1 (98-112 tiles on 256 CUs) and layer4.x.conv3 (K = 512: the
+// tile's residual + store epilogue is as long as its K loop): the schedule's 1.36 PFLOP/s shows at K >= 2048 with whole rounds of tiles only.
+struct G8Shape { int h, cin, cout, two_sources; };
+constexpr G8Shape kG8[] = {{14, 1024, 256, 0}, {14, 1024, 512, 0}, {14, 768, 1024, 1}, {7, 1536, 2048, 1}};
 int g8_tile(const ConvArgs& a) {
     if (!g_use_g8 || !is_g8_shape(a) || a.N < 48) return 0;
     if (g_use_g8 == 2) return kTileG8;
     if (g_use_g8 == 3) return kTileG8N7;
+    for (const G8Shape& g : kG8)
+        if (g.h == a.Ho && a.Ho == a.Wo && g.cin == a.Ktot && g.cout == a.Cout && (g.two_sources != 0) == (a.x2 != nullptr) && a.stride == 1 && !a.res)
+            return tiles_of(a, kTileG8N7) >= 200 ? kTileG8N7 : 0;
     return 0;
 }
 int auto_tile(const ConvArgs& a) {
@@ -958,20 +967,10 @@ hipError_t launch_bneck_block2(const void* t1, int n, const void* w2, const floa
     return hipGetLastError();
 }
 
-// bneck_body1_kernel (round 4: the layer1 body without a weight-stage ring) replaces bneck_block1_kernel where its bit is set: 1 = plain identity, next
-// conv1 256 -> 64 (layer1.1), 2 = next conv1 256 -> 128 (layer1.2), 4 = downsample identity (layer1.0).  A/B knob: R50_BODY1 / option "body1".
-int g_body1 = [] { const char* v = std::getenv("R50_BODY1"); return v ? std::atoi(v) : 0; }();
-constexpr size_t kBody1PackedBytes = 25 * 8192;      // at most 9 + 4 x 4 stages of 8 KB
-hipError_t pack_body1_weights(const void* w2, const void* w3, const void* wd, const void* w1, int c1, void* wp, hipStream_t s) {
-    const int ns = 9 + 4 * (1 + (wd ? 1 : 0) + c1 / 64);
-    hipLaunchKernelGGL(body1_pack_kernel, dim3(ns * 2), dim3(256), 0, s, (const __bf16*)w2, (const __bf16*)w3, (const __bf16*)wd, (const __bf16*)w1, c1, (__bf16*)wp);
-    return hipGetLastError();
-}
-bool body1_selected(int c1, bool ds) { return (g_body1 & (ds ? 4 : (c1 == 128 ? 2 : 1))) != 0; }
 // layer1.1 / .2 bottleneck body in one launch (kernels.h: bneck_block1_kernel): conv2 + conv3 + identity + ReLU + the next conv1 (c1 = 64 or 128)
 hipError_t launch_bneck_block1(const void* t1, int n, const void* w2, const float* b2, const void* w3, const float* b3, const void* res,
                                void* out, const void* w1, int c1, const float* b1, void* y1n, hipStream_t s, int et = 0,
-                               const void* wd = nullptr, const float* bd = nullptr, const void* wp = nullptr) {
+                               const void* wd = nullptr, const float* bd = nullptr) {
     if (!t1 || !w2 || !b2 || !w3 || !b3 || !res || !out || !w1 || !b1 || !y1n || n <= 0 || (long long)n * 3136 * 512 >= (1ll << 31)) return hipErrorInvalidValue;
     if (c1 != 64 && c1 != 128) return hipErrorInvalidValue;
     if ((wd == nullptr) != (bd == nullptr) || (wd && c1 != 64)) return hipErrorInvalidValue;       // downsample form: layer1.0 (next conv1 256 -> 64)
@@ -984,20 +983,10 @@ hipError_t launch_bneck_block1(const void* t1, int n, const void* w2, const floa
     Block1Args a;
     a.t1 = (const __bf16*)t1; a.w2 = (const __bf16*)w2; a.b2 = b2; a.w3 = (const __bf16*)w3; a.b3 = b3; a.res = (const __bf16*)res;
     a.out = (__bf16*)out; a.w1 = (const __bf16*)w1; a.b1 = b1; a.y1n = (__bf16*)y1n; a.N = n; a.n_tiles = 14 * n;
-    a.wd = (const __bf16*)wd; a.bd = bd; a.wp = (const __bf16*)wp;
+    a.wd = (const __bf16*)wd; a.bd = bd;
     const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
-    void (*kern)(const Block1Args);
-    if (wp) {                                  // bneck_body1_kernel: eight waves, weights / identity through registers (kernels.h: its LDS map)
-        const size_t lds1 = 11 * 32 * 128 + (wd ? 4 : 3) * 224 * 128 + (448 + 256) * 4;
-        if (wd) kern = et == 1 ? bneck_body1_kernel<1, 64, true> : bneck_body1_kernel<0, 64, true>;
-        else if (c1 == 64) kern = et == 1 ? bneck_body1_kernel<1, 64> : bneck_body1_kernel<0, 64>;
-        else kern = et == 1 ? bneck_body1_kernel<1, 128> : bneck_body1_kernel<0, 128>;
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        if (e1 != hipSuccess) return e1;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds1, s, a);
-        return hipGetLastError();
-    }
     constexpr size_t lds = 11 * 32 * 128 + 3 * 224 * 128 + 3 * 8192 + (448 + 256) * 4;       // 158,464 (kernels.h: LDS map; bd behind b1)
+    void (*kern)(const Block1Args);
     if (wd) kern = et == 1 ? bneck_block1_kernel<1, 64, true> : bneck_block1_kernel<0, 64, true>;
     else if (c1 == 64) kern = et == 1 ? bneck_block1_kernel<1, 64> : bneck_block1_kernel<0, 64>;
     else kern = et == 1 ? bneck_block1_kernel<1, 128> : bneck_block1_kernel<0, 128>;
@@ -1432,7 +1421,7 @@ after_pool:
                 prof_begin(h, s, rb, PC_BLOCK2, 2.0 * m * (64.0 * 576 + 2 * 256.0 * 64 + 64.0 * 256),
                            2.0 * (m * (64.0 + 64 + 256 + 64) + 64.0 * 576 + 2 * 256.0 * 64 + 64.0 * 256), (int)(&c2 - &h->convs[0]));
                 e = launch_bneck_block1(buf[fr[0]], n, c2.w, c2.bias, c3.w, c3.bias, buf[cur], buf[fr[3]], nx->w, 64, nx->bias, buf[fr[1]], s, et,
-                                        cdp->w, cdp->bias, body1_selected(64, true) ? h->body1_wp[0] : nullptr);
+                                        cdp->w, cdp->bias);
                 prof_end(h, s, rb);
                 if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_block1 (downsample) launch (" + c2.conv_key + "): " + hipGetErrorString(e));
                 pre_t1 = fr[1];
@@ -1449,8 +1438,7 @@ after_pool:
                 EvRec rb{};
                 prof_begin(h, s, rb, PC_BLOCK2, 2.0 * m * (64.0 * 576 + 256.0 * 64 + (double)nx->cout * 256),
                            2.0 * (m * (64.0 + 256 + 256 + nx->cout) + 64.0 * 576 + 256.0 * 64 + (double)nx->cout * 256), (int)(&c2 - &h->convs[0]));
-                e = launch_bneck_block1(buf[fr[0]], n, c2.w, c2.bias, c3.w, c3.bias, buf[cur], buf[fr[3]], nx->w, nx->cout, nx->bias, buf[fr[1]], s, et,
-                                        nullptr, nullptr, (b < 3 && body1_selected(nx->cout, false)) ? h->body1_wp[b] : nullptr);
+                e = launch_bneck_block1(buf[fr[0]], n, c2.w, c2.bias, c3.w, c3.bias, buf[cur], buf[fr[3]], nx->w, nx->cout, nx->bias, buf[fr[1]], s, et);
                 prof_end(h, s, rb);
                 if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_block1 launch (" + c2.conv_key + "): " + hipGetErrorString(e));
                 pre_t1 = fr[1];
@@ -1586,7 +1574,6 @@ void free_weights(r50_handle* h) {        // the buffers a sharer reads through 
         L.w = nullptr; L.bias = nullptr; L.bias_scaled = nullptr;
     }
     for (auto& p : h->tail3_wp) { if (own && p) (void)hipFree(p); p = nullptr; }
-    for (auto& p : h->body1_wp) { if (own && p) (void)hipFree(p); p = nullptr; }
     if (own && h->catchain_wp) (void)hipFree(h->catchain_wp);
     h->catchain_wp = nullptr;
     for (int i = 0; i < 4; ++i) {
@@ -1758,7 +1745,6 @@ int r50_share_weights(r50_handle* h, r50_handle* from) {
     }
     for (int i = 0; i < 4; ++i) { h->cat_w[i] = from->cat_w[i]; h->cat_bias[i] = from->cat_bias[i]; h->cat_acc_scale[i] = from->cat_acc_scale[i]; }
     for (int b = 0; b < 8; ++b) h->tail3_wp[b] = from->tail3_wp[b];
-    for (int b = 0; b < 3; ++b) h->body1_wp[b] = from->body1_wp[b];
     h->catchain_wp = from->catchain_wp;
     h->owner = from;
     ++from->sharers;
@@ -1769,6 +1755,10 @@ int r50_share_weights(r50_handle* h, r50_handle* from) {
 int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensors) {
     if (!h) return fail(nullptr, R50_ERR_INVALID, "r50_load_weights: null handle");
     if (!tensors || n_tensors <= 0) return fail(h, R50_ERR_INVALID, "r50_load_weights: no tensors");
+    // handles that take part in r50_share_weights: a sharer would write the folded weights into its OWNER's buffers (and leak what it allocates beside
+    // them); an owner with sharers would repack the weights under lanes that may be in mid-forward on other streams
+    if (h->owner || h->sharers > 0 || h->zombie)
+        return fail(h, R50_ERR_STATE, "r50_load_weights: this handle shares its weight buffers (r50_share_weights): load into a fresh handle instead");
     HIP_TRY(h, hipSetDevice(h->device));
     std::map<std::string, const r50_tensor_desc*> by_name;
     for (int i = 0; i < n_tensors; ++i) {
@@ -1864,17 +1854,6 @@ int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensor
                         nx.cin == 512 && nx.cout == 128) {
                         if (!h->catchain_wp) HIP_TRY(h, hipMalloc((void**)&h->catchain_wp, kCatChainPackedBytes));
                         HIP_TRY(h, pack_catchain_weights(h->cat_w[1], nx.w, h->catchain_wp, nullptr));
-                    }
-                }
-                if (si == 0 && b < 3 && inx < h->convs.size()) {      // layer1 bodies: conv2, conv3, (block 0: the downsample conv,) the next conv1
-                    const ConvLayer& c2 = h->convs[li + 1];
-                    const ConvLayer& c3 = h->convs[i3];
-                    const ConvLayer& nx = h->convs[inx];
-                    const ConvLayer* cd = (b == 0) ? &h->convs[li + 3] : nullptr;
-                    if (c2.ks == 3 && c2.cin == 64 && c2.cout == 64 && c3.ks == 1 && c3.cin == 64 && c3.cout == 256 && nx.ks == 1 && nx.cin == 256 &&
-                        (nx.cout == 64 || nx.cout == 128) && (!cd || (cd->ks == 1 && cd->cin == 64 && cd->cout == 256 && nx.cout == 64))) {
-                        if (!h->body1_wp[b]) HIP_TRY(h, hipMalloc((void**)&h->body1_wp[b], kBody1PackedBytes));
-                        HIP_TRY(h, pack_body1_weights(c2.w, c3.w, cd ? cd->w : nullptr, nx.w, nx.cout, h->body1_wp[b], nullptr));
                     }
                 }
                 if (si == 2 && b > 0 && b < 8 && inx < h->convs.size()) {
@@ -2009,7 +1988,6 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "fuse_block2") h->fuse_block2 = value ? 1 : 0;
     else if (k == "fuse_block1") { if (value < 0 || value > 3) return fail(h, R50_ERR_INVALID, "fuse_block1 must be 0 .. 3"); h->fuse_block1 = (int)value; }
     else if (k == "xres_variant") g_xres_variant = (int)value;        // process-wide A/B knob
-    else if (k == "body1") { if (value < 0 || value > 7) return fail(h, R50_ERR_INVALID, "body1 must be 0 .. 7"); g_body1 = (int)value; }   // process-wide A/B knob
     else if (k == "use_g8") { if (value < 0 || value > 3) return fail(h, R50_ERR_INVALID, "use_g8 must be 0 .. 3"); g_use_g8 = (int)value; }   // process-wide A/B knob
     else if (k == "use_s2") g_use_s2 = (int)value;                     // process-wide A/B knob: 0 = generic tiles for the stride-2 3x3 shapes
     else if (k == "cu_cap") { if (value < 0 || value > 4096) return fail(h, R50_ERR_INVALID, "cu_cap must be in [0,4096]"); g_cu_cap = (int)value; g_num_cus = 0; }
@@ -2034,7 +2012,6 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "tail3_variant") *value = g_tail3_variant;
     else if (k == "tail3_bp") *value = g_tail3_bp;
     else if (k == "use_g8") *value = g_use_g8;
-    else if (k == "body1") *value = g_body1;
     else if (k == "fuse_cat_chain") *value = h->fuse_cat_chain;
     else if (k == "fuse_tail3_last") *value = h->fuse_tail3_last;
     else if (k == "fuse_fp8_handover") *value = h->fuse_fp8_handover;
@@ -2215,16 +2192,7 @@ int r50_op_bneck_block2(const void* t1, int n, const void* w2, const float* b2, 
 int r50_op_bneck_block1_ds(const void* t1, int n, const void* w2, const float* b2, const void* w3, const float* b3, const void* x, const void* wd,
                            const float* bd, void* out, const void* w1, const float* b1, void* y1n, void* stream) {
     if (!wd || !bd) return fail(nullptr, R50_ERR_INVALID, "r50_op_bneck_block1_ds: null downsample weights");
-    hipError_t e;
-    if (body1_selected(64, true) && w2 && w3 && w1) {        // plain weight matrices in, packed per call (stream-ordered scratch, as r50_op_bneck_tail does)
-        void* wp = nullptr;
-        if (hipMallocAsync(&wp, kBody1PackedBytes, (hipStream_t)stream) != hipSuccess || !wp) return fail(nullptr, R50_ERR_HIP, "r50_op_bneck_block1_ds: hipMallocAsync");
-        e = pack_body1_weights(w2, w3, wd, w1, 64, wp, (hipStream_t)stream);
-        if (e == hipSuccess) e = launch_bneck_block1(t1, n, w2, b2, w3, b3, x, out, w1, 64, b1, y1n, (hipStream_t)stream, 0, wd, bd, wp);
-        const hipError_t ef = hipFreeAsync(wp, (hipStream_t)stream);
-        if (e == hipSuccess) e = ef;
-    } else
-    e = launch_bneck_block1(t1, n, w2, b2, w3, b3, x, out, w1, 64, b1, y1n, (hipStream_t)stream, 0, wd, bd);
+    const hipError_t e = launch_bneck_block1(t1, n, w2, b2, w3, b3, x, out, w1, 64, b1, y1n, (hipStream_t)stream, 0, wd, bd);
     if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
                                      std::string("r50_op_bneck_block1_ds: ") + hipGetErrorString(e));
     return R50_OK;
@@ -2248,16 +2216,7 @@ int r50_op_bneck_cat_chain(const void* t2, const void* x, int n, int ow, const v
 
 int r50_op_bneck_block1(const void* t1, int n, const void* w2, const float* b2, const void* w3, const float* b3, const void* res,
                         void* out, const void* w1, int c1, const float* b1, void* y1n, void* stream) {
-    hipError_t e;
-    if ((c1 == 64 || c1 == 128) && body1_selected(c1, false) && w2 && w3 && w1) {
-        void* wp = nullptr;
-        if (hipMallocAsync(&wp, kBody1PackedBytes, (hipStream_t)stream) != hipSuccess || !wp) return fail(nullptr, R50_ERR_HIP, "r50_op_bneck_block1: hipMallocAsync");
-        e = pack_body1_weights(w2, w3, nullptr, w1, c1, wp, (hipStream_t)stream);
-        if (e == hipSuccess) e = launch_bneck_block1(t1, n, w2, b2, w3, b3, res, out, w1, c1, b1, y1n, (hipStream_t)stream, 0, nullptr, nullptr, wp);
-        const hipError_t ef = hipFreeAsync(wp, (hipStream_t)stream);
-        if (e == hipSuccess) e = ef;
-    } else
-    e = launch_bneck_block1(t1, n, w2, b2, w3, b3, res, out, w1, c1, b1, y1n, (hipStream_t)stream);
+    const hipError_t e = launch_bneck_block1(t1, n, w2, b2, w3, b3, res, out, w1, c1, b1, y1n, (hipStream_t)stream);
     if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? R50_ERR_INVALID : R50_ERR_HIP,
                                      std::string("r50_op_bneck_block1: ") + hipGetErrorString(e));
     return R50_OK;

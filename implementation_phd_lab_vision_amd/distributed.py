@@ -45,11 +45,19 @@ class RankContext:
         return self.backend is not None
 
 
+def single_rank_group_requested(env=None) -> bool:
+    """ONE rank joins a process group only when a launcher described a complete rendezvous -- RANK, WORLD_SIZE and MASTER_PORT all present, as
+    torchrun sets them -- and ``R50_SINGLE_RANK_GROUP`` is not "0".  A scheduler or container that merely exports RANK=0 WORLD_SIZE=1 (no
+    MASTER_PORT) gets a plain single process: no env:// rendezvous to fail in, no RCCL init, no gloo side group."""
+    env = os.environ if env is None else env
+    return all(k in env for k in ("RANK", "WORLD_SIZE", "MASTER_PORT")) and env.get("R50_SINGLE_RANK_GROUP", "1") != "0"
+
+
 def init_from_env(use_gpu: bool) -> RankContext:
     """Join the process group torchrun described (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
     backend "nccl" IS RCCL on ROCm; CPU rehearsals use gloo."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1 and not ("RANK" in os.environ and "WORLD_SIZE" in os.environ and os.environ.get("R50_SINGLE_RANK_GROUP", "1") != "0"):
+    if world <= 1 and not single_rank_group_requested():
         return RankContext()
     rank = int(os.environ["RANK"])
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

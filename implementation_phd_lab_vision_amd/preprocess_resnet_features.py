@@ -457,8 +457,8 @@ def main(argv: Optional[List[str]] = None) -> None:
         backbone(warm)
     torch.cuda.synchronize(device)
     if n_lanes > 1:
-        gain = backbone.tune(warm)
-        log(f"Lanes      : {n_lanes} lanes run at {gain:.3f} x one lane on the warm-up batch")
+        backbone.tune(warm)               # informational ratio; too small a warm-up batch is not measured at all, a loss falls back to one lane
+        log(f"Lanes      : {backbone.tune_mode} on the warm-up batch")
     del warm
     log("✓ Warmup complete\n")
 

@@ -72,7 +72,8 @@ int r50_create(r50_handle** out, int device_id, int precision, int max_batch);
  * Takes every conv weight and BN weight/bias/running_mean/running_var by torchvision key name
  * (fc.* and num_batches_tracked are not needed), folds eval-mode BN (eps 1e-5) into conv
  * weight+bias in fp32, converts to bf16 and uploads in the kernels' packed layout.
- * The caller keeps ownership of the host buffers. */
+ * The caller keeps ownership of the host buffers.  R50_ERR_STATE for a handle that takes part in r50_share_weights (a sharer, or an
+ * owner that still has sharers): its buffers are read by other handles' launches -- load into a fresh handle instead. */
 int r50_load_weights(r50_handle* h, const r50_tensor_desc* tensors, int n_tensors);
 
 /* Instead of r50_load_weights: `h` (fresh from r50_create, same device and precision as `from`, bf16 or fp16) reads the folded / packed weight buffers

@@ -100,3 +100,35 @@ def test_pmc_summary_counts_full_batch_launches_only(tmp_path):
     # without the guard the check launches pull the averages down (what round 2 committed)
     res0, table0 = P.summarize([str(ff)], [str(wf)], forwards=0, log=log)
     assert res0["conv1"]["launches_counted"] == 8 and res0["conv1"]["fetch_bytes_per_launch_raw"] < 0.9 * 77300.0 * 1024 and table0 is None
+
+
+def test_lane_plan_falls_back_to_one_lane_when_the_lanes_cost_time():
+    """BackboneLanes.tune's decision (`fp8_b512` reported 122.1 k frames/s on two lanes beside its own `single_lane` 125.7 k):
+    a last ratio below 1 means submit() deals every batch to lane 0; between 1 and the tuning target both lanes stay."""
+    from implementation_phd_lab_vision_amd.backbone import BackboneLanes
+    assert BackboneLanes.lane_plan([], 2)[0] == 2
+    assert BackboneLanes.lane_plan([1.07], 2) == (2, "2 lanes (1.070 x one lane)")
+    n, mode = BackboneLanes.lane_plan([0.99, 0.971], 2)
+    assert n == 1 and "fallback" in mode and "0.971" in mode
+    n, mode = BackboneLanes.lane_plan([0.99, 1.005], 2)
+    assert n == 2 and "below the tuning target" in mode
+    assert BackboneLanes.lane_plan([0.5], 1) == (1, "one lane")
+    assert BackboneLanes.lane_plan([0.97], 2, drop_below=0.0)[0] == 2
+
+
+def test_roofline_object_describes_the_largest_class(bench):
+    """The `roofline` object of the bench line is the kernel class with the largest ms_per_step, carries both
+    fractions and its bound = the larger one; the igemm class rides beside it."""
+    prof = {"igemm": {"launches": 38, "ms": 2.2, "flops": 1.97e12, "bytes": 4.0e9},
+            "bneck_block2": {"launches": 12, "ms": 2.3, "flops": 1.4e12, "bytes": 8.7e9},
+            "bneck_tail3": {"launches": 10, "ms": 0.7, "flops": 0.5e12, "bytes": 2.5e9},
+            "conv1": {"launches": 2, "ms": 0.28, "flops": 0.13e12, "bytes": 0.72e9},
+            "avgpool": {"launches": 2, "ms": 0.02, "flops": 0.0, "bytes": 0.1e9}}
+    r = bench.roofline_object(prof, steps=2, precision="bf16", traffic={"bneck_block": {"hbm_bytes_per_launch": 8.0e8}}, traffic_source="static")
+    assert r["class"] == "bneck_block2" and r["bound"] == "hbm" and r["unit"] == "GB/s"
+    assert r["achieved"] == pytest.approx(8.7e9 / 2.3e-3 / 1e9) and r["frac"] == pytest.approx(r["achieved"] / 8000.0)
+    assert r["frac_of_mfma_peak"] == pytest.approx(1.4e12 / 2.3e-3 / 1e12 / 2500.0) and r["traffic"] == 8.0e8
+    assert r["launches_per_step"] == 6 and r["ms_per_step"] == pytest.approx(1.15)
+    ig = r["classes"]["igemm"]
+    assert ig["bound"] == "mfma" and ig["frac"] == pytest.approx(1.97e12 / 2.2e-3 / 1e12 / 2500.0) and ig["launches_per_step"] == 19
+    assert set(r["classes"]) == {"igemm", "bneck_tail3", "conv1", "avgpool"}

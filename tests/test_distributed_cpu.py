@@ -157,3 +157,13 @@ def test_compute_rounds_do_not_wait_for_a_slow_packer(tmp_path, monkeypatch):
     assert throttled["clips_packed_at_compute_done"] >= 14, throttled
     assert free["compute_done_s"] <= free["total_s"] and throttled["compute_done_s"] <= throttled["total_s"]
     assert_same_feature_cache(tmp_path / "slots16", tmp_path / "slots1")
+
+
+def test_one_rank_group_needs_a_complete_rendezvous():
+    """ADVICE r3: a container that exports RANK=0 WORLD_SIZE=1 without MASTER_PORT runs as a plain single process (no env:// rendezvous to
+    fail in); torchrun's environment (MASTER_PORT present) joins the one-rank group unless R50_SINGLE_RANK_GROUP=0."""
+    from implementation_phd_lab_vision_amd.distributed import single_rank_group_requested
+    assert not single_rank_group_requested({})
+    assert not single_rank_group_requested({"RANK": "0", "WORLD_SIZE": "1"})
+    assert single_rank_group_requested({"RANK": "0", "WORLD_SIZE": "1", "MASTER_PORT": "29500"})
+    assert not single_rank_group_requested({"RANK": "0", "WORLD_SIZE": "1", "MASTER_PORT": "29500", "R50_SINGLE_RANK_GROUP": "0"})

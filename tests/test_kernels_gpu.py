@@ -248,38 +248,12 @@ def test_bneck_block2_equals_unfused(lib_built, n, chain):
         assert y1n is None
 
 
-class _process_option:
-    """Sets a process-wide library option (through any handle) for the duration of a test."""
-    def __init__(self, key, value):
-        self.key, self.value = key, value
-
-    def __enter__(self):
-        from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
-        self.bb = ResNet50Backbone(seed=0, max_batch=2).to(_dev())
-        self.old = self.bb.get_option(self.key)
-        self.bb.set_option(self.key, self.value)
-        return self
-
-    def __exit__(self, *exc):
-        self.bb.set_option(self.key, self.old)
-        self.bb.close()
-        return False
-
-
-@pytest.mark.parametrize("body1", [0, 7], ids=["ring_kernel", "body1_kernel"])
 @pytest.mark.parametrize("c1", [64, 128])
 @pytest.mark.parametrize("n", [1, 3, 20, 41])
-def test_bneck_block1_equals_unfused(lib_built, n, c1, body1):
+def test_bneck_block1_equals_unfused(lib_built, n, c1):
     """Layer1 bottleneck body in one launch: block output and next t1 are the same bits as the resident-weights 3x3 launch followed by
-    the 1x1 igemm launches (n = 20: 280 tiles, more than one per workgroup; n = 41: 574 tiles, up to three per workgroup: the register-staged
-    band / identity prefetch of bneck_body1_kernel runs two tiles ahead).  body1 = 7: bneck_body1_kernel (weights and identity through
-    registers, six barriers per tile) instead of bneck_block1_kernel (weight-stage ring)."""
+    the 1x1 igemm launches (n = 20: 280 tiles, more than one per workgroup; n = 41: 574 tiles, up to three per workgroup)."""
     from implementation_phd_lab_vision_amd import ops
-    with _process_option("body1", body1):
-        _block1_case(ops, n, c1)
-
-
-def _block1_case(ops, n, c1):
     g = torch.Generator().manual_seed(5100 + n + c1)
     d = _dev()
     t1 = _rand_bf16((n, 56, 56, 64), g).clamp_(min=0).to(d)
@@ -299,18 +273,12 @@ def _block1_case(ops, n, c1):
     assert torch.equal(y1n, y1_ref), f"next conv1 differs: max |diff| {float((y1n.float() - y1_ref.float()).abs().max())}"
 
 
-@pytest.mark.parametrize("body1", [0, 7], ids=["ring_kernel", "body1_kernel"])
 @pytest.mark.parametrize("n", [1, 3, 20, 41])
-def test_bneck_block1_downsample_equals_unfused(lib_built, n, body1):
-    """layer1.0's body in one launch (bneck_block1_kernel<.., DS> / bneck_body1_kernel<.., DS>): the identity is the downsample conv of the block
-    input, computed in the kernel and rounded to bf16 as the separate launch stores it.  Block output and next t1 are the same bits as the
-    resident-weights 3x3 launch, the 1x1 downsample launch, the 1x1 conv3 launch with that identity, and the next 1x1 launch."""
+def test_bneck_block1_downsample_equals_unfused(lib_built, n):
+    """layer1.0's body in one launch (bneck_block1_kernel<.., DS>): the identity is the downsample conv of the block input, computed in the
+    kernel and rounded to bf16 as the separate launch stores it.  Block output and next t1 are the same bits as the resident-weights 3x3 launch,
+    the 1x1 downsample launch, the 1x1 conv3 launch with that identity, and the next 1x1 launch."""
     from implementation_phd_lab_vision_amd import ops
-    with _process_option("body1", body1):
-        _block1_ds_case(ops, n)
-
-
-def _block1_ds_case(ops, n):
     g = torch.Generator().manual_seed(5300 + n)
     d = _dev()
     t1 = _rand_bf16((n, 56, 56, 64), g).clamp_(min=0).to(d)
