@@ -4379,61 +4379,6 @@ struct Block1Args {
     __bf16* y1n;          // (M, C1N)
     int N;
     int n_tiles;          // 14 N
-#if defined(R50_STAMP)    // diagnostic build (scripts/stamp_block1.py): per-wave cycle sums, 8 slots per wave
-    unsigned long long* dbg;
-#endif
-};
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {          // f(std::integral_constant<int, I>{}) for I in [I, N): the index is a constant expression in the body
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// The loaders' vmcnt bookkeeping of bneck_block1_kernel as a compile-time table.  A loader wave's vector-memory operations per tile are a fixed
-// sequence (per position p: the weight stage p + 2 FIRST, then identity rows where due, then a slice of the next tile's band); vmcnt retires in
-// order, so "X has landed" = "all but the n operations issued behind X are done".  `due(p, first_tile, has_next)` simulates the sequence and
-// returns the n to wait for at position p: the smallest over what the consumers read behind that position's barrier (stage p + 1 always; the identity
-// rows of chunk c at the A(c) position; the next tile's band at the last position).
-template <int C1N, bool DS>
-struct Block1LoaderSched {
-    // the next tile's band (11 passes) over the first six positions of the chunk phase, 2 2 2 2 2 1: done at least two positions before the tile's last barrier
-    static constexpr int WPASS = 2, NCONV = 9, NA = DS ? 2 : 1, LCH = NA + C1N / 64, SPT = NCONV + 4 * LCH, XPASS = 11, BAND_POS = 6, IDP = 7;
-    struct State { int after_stage, after_id, after_band; };
-    static constexpr State prologue() { return State{IDP, 0, WPASS + IDP}; }      // issued: stage 0, band, stage 1, identity rows; (stage 0 + band waited for)
-    static constexpr int band_i0(int k) { return 2 * k; }
-    static constexpr int band_n(int k) { return k < 5 ? 2 : 1; }
-    static constexpr bool id_pos(int p, bool has_next) {
-        const int q = p - NCONV;
-        if (q < 0) return false;
-        const int c = q / LCH, r = q - c * LCH;
-        return (!DS && r == NA && c < 3) || (r == NA && c == 3 && has_next);
-    }
-    // runs positions [0, p_stop] of one tile from state `st`; returns the wait count of position p_stop (and the state behind it in *out)
-    static constexpr int run(State st, bool has_next, bool last_stages, int p_stop, State* out) {
-        int due = 0;
-        for (int p = 0; p <= p_stop; ++p) {
-            const int q = p - NCONV, c = q >= 0 ? q / LCH : -1, r = q >= 0 ? q - c * LCH : -1;
-            due = st.after_stage;
-            const bool stg = (p + 2 < SPT) || last_stages;
-            if (stg) { due += WPASS; st.after_id += WPASS; st.after_band += WPASS; st.after_stage = 0; }
-            if (id_pos(p, has_next)) { due += IDP; st.after_stage += IDP; st.after_band += IDP; st.after_id = 0; }
-            if (has_next && p >= NCONV && p < NCONV + BAND_POS) {
-                const int n = band_n(p - NCONV);
-                due += n; st.after_stage += n; st.after_id += n; st.after_band = 0;
-            }
-            if (r == 0 && (!DS || c == 0) && st.after_id < due) due = st.after_id;
-            if (p == SPT - 1 && has_next && st.after_band < due) due = st.after_band;
-        }
-        if (out) *out = st;
-        return due;
-    }
-    static constexpr State steady() { State e{0, 0, 0}; (void)run(prologue(), true, true, SPT - 1, &e); return e; }   // behind any tile that has a next one
-    static constexpr int due(int p, bool first_tile, bool has_next) {
-        return run(first_tile ? prologue() : steady(), has_next, has_next, p, nullptr);
-    }
 };
 
 template <int ET, int C1N, bool DS = false>
@@ -4471,15 +4416,6 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
 
     if (wave >= 8) {
         // =============================== loader waves ===============================================
-        // Round 4.  vmcnt retires IN ORDER: "stage p + 1 has landed" can only be learnt once everything this wave issued BEFORE that stage's
-        // DMAs has landed too.  Rounds 2-3 issued identity rows, band passes and the copy-out's stores in front of the iteration's weight stage
-        // and waited, one barrier later, for everything of that iteration: 8 of a tile's 17 barrier intervals waited an HBM round trip for an
-        // 8-KB stage that comes from L2 (only the four identity waits are real dependences).  Now, per iteration:
-        //   1. the weight stage FIRST -- what this iteration issues behind it (HBM class) is younger and never stands in front of it;
-        //   2. identity rows of the next chunk / the next tile's chunk 0, a slice of the next tile's band (spread over six chunk positions);
-        //   3. ONE wait for the oldest thing due: stage p + 1 always (`after_stage` operations are younger), the identity rows of chunk c at the
-        //      A(c) position (`after_id`), the next tile's band at the tile's last position (`after_band`).
-        // The copy-out of out_c moved to the consumer waves (below): it was 56 of the loaders' ~140 instructions per chunk, all in one interval.
         const int lw = wave - 8, lt = tid - 512;
         const int srow = lt >> 3, slot = lt & 7;
         const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w2), 0, 64u * 576u * 2u, 0x00020000);
@@ -4488,6 +4424,7 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.t1), 0, (unsigned)a.N * (3136u * 128u), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.N * (3136u * (DS ? 128u : 512u)), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_wd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(DS ? a.wd : a.w3), 0, 256u * 64u * 2u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.N * (3136u * 512u), 0x00020000);
         unsigned w2v[WPASS], w3v[WPASS], w1v[WPASS], x_voff[XPASS], rv[7], rvx[7];
 #pragma unroll
         for (int i = 0; i < WPASS; ++i) {
@@ -4499,7 +4436,7 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
             w1v[i] = ((unsigned)cl * 256u + ch) * 2u;
         }
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {             // rows of a 64-channel chunk of the identity: row R = 32 i + srow of the tile
+        for (int i = 0; i < 7; ++i) {             // rows of a 64-channel chunk of the identity / block output: row R = 32 i + srow of the tile
             const int R = 32 * i + srow;
             rv[i] = ((unsigned)R * 256u + (unsigned)((slot ^ (R & 7)) * 8)) * 2u;
             rvx[i] = ((unsigned)R * 64u + (unsigned)((slot ^ (R & 7)) * 8)) * 2u;          // DS: the same rows of the 64-channel block input
@@ -4521,12 +4458,19 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
                 if (i >= i0 && i < i1)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + XB_OFF + i * 4096 + lw * 1024), 16, x_voff[i], 0, 0, 0);
         };
-        auto tile_pix = [&](int tile) { return (unsigned)((tile / 14) * 3136 + (tile % 14) * NPX); };
         auto issue_res = [&](unsigned tile_pix0, int c) {       // 7 DMAs per wave: identity rows of chunk c (DS: the tile's block-input rows)
             const int sofs = __builtin_amdgcn_readfirstlane(DS ? (int)(tile_pix0 * 128u) : (int)(tile_pix0 * 512u) + c * 128);
 #pragma unroll
             for (int i = 0; i < 7; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(smem + RESB_OFF + i * 4096 + lw * 1024), 16, DS ? rvx[i] : rv[i], sofs, 0, 0);
+        };
+        auto copy_out = [&](unsigned tile_pix0, int c) {        // 7 LDS reads + 7 stores per wave: out_c -> block output
+            const int sofs = __builtin_amdgcn_readfirstlane((int)(tile_pix0 * 512u) + c * 128);
+            u32x4 v[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) v[i] = *reinterpret_cast<const u32x4*>(smem + OUTC_OFF + i * 4096 + lt * 16);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, rv[i], sofs, 0);
         };
         int ring = 0;                             // ring slot of the next stage to issue
         auto stage_issue = [&](int p) {           // stage p (0 .. SPT-1) of a tile; 2 DMAs per wave
@@ -4552,67 +4496,56 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
                 }
             }
         };
-        // prologue: stage 0, the band, stage 1, chunk 0's identity rows (DS: the block-input rows) -- in that order: stage 0 and the band have to have
-        // landed at the first barrier (2 + 7 younger operations may be in flight)
+        auto wait_younger = [&](int n) { wait_vmcnt(n); };          // all but the n youngest vector-memory operations of this wave are complete
         decode_band(first);
-        stage_issue(0);
         issue_band(0, XPASS);
+        stage_issue(0);
         stage_issue(1);
-        issue_res(tile_pix(first), 0);
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WPASS + 7) : "memory");       // (bias writes done)
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");       // band and stage 0 landed (stage 1 may be in flight); bias writes done
         __builtin_amdgcn_s_barrier();
-        using Sched = Block1LoaderSched<C1N, DS>;
-        static_assert(Sched::SPT == SPT && Sched::LCH == LCH && Sched::NA == NA && Sched::XPASS == XPASS && Sched::WPASS == WPASS, "schedule table = kernel geometry");
-        bool first_tile = true;
-        R50_STAMP_DECL
+        int carry = 0;                            // stores of the previous iteration (issued behind its DMAs)
 #pragma unroll 1
         for (int tile = first; tile < a.n_tiles; tile += grid) {
             const bool has_next = tile + grid < a.n_tiles;
-            const unsigned tile_pix0 = tile_pix(tile);
-            // (round 3: the position loop is unrolled -- every decision below folds at compile time; round 4: as a static_for, so that the wait counts are constants too)
-            static_for<0, SPT>([&](auto p_c) {
-                constexpr int p = decltype(p_c)::value;
-                constexpr int q = p - NCONV, c = q >= 0 ? q / LCH : -1, r = q >= 0 ? q - c * LCH : -1;
+            const unsigned tile_pix0 = (unsigned)((tile / 14) * 3136 + (tile % 14) * NPX);
+            B2_LOADER_LOOP                                            // (round 3: unrolled, as bneck_block2_kernel's)
+            for (int p = 0; p < SPT; ++p) {
+                const int q = p - NCONV, c = q >= 0 ? q / LCH : -1, r = q >= 0 ? q - c * LCH : -1;
                 // the consumers' extra barriers: T2 complete (in front of the first A stage), OUTC(c) complete (in front of the first B stage)
-                if (p == NCONV || r == NA) { __builtin_amdgcn_s_barrier(); R50_MARK(3) }
-                // 1. the weight stage two positions ahead, FIRST
-                if ((p + 2 < SPT) || has_next) stage_issue(p + 2 < SPT ? p + 2 : p + 2 - SPT);
-                // 2. identity rows: chunk c + 1 right behind E(c) (RESB is free behind the OUTC(c) barrier); the NEXT tile's chunk 0 (DS: its block-input
-                //    rows) behind this tile's last read of RESB -- E(3), DS: D(3) -- i.e. at the first B position of chunk 3
-                if (!DS && r == NA && c < 3) issue_res(tile_pix0, c + 1);
-                if (r == NA && c == 3 && has_next) issue_res(tile_pix(tile + grid), 0);
-                // 3. a slice of the next tile's band: its buffer is dead once conv2 is done (behind the T2 barrier)
-                if (has_next && p >= NCONV && p < NCONV + Sched::BAND_POS) {
+                if (p == NCONV || r == NA) __builtin_amdgcn_s_barrier();
+                int younger = carry;
+                carry = 0;
+                // identity rows: chunk 0 two stages before the first A stage (RESB is free since the previous tile's last E), chunk c + 1
+                // right behind E(c) -- they have to be in LDS one barrier later (A(c + 1)), or two (C1N = 128)
+                if (p == NCONV - 2) { issue_res(tile_pix0, 0); younger += 7; }
+                if (!DS && r == 1 && c < 3) { issue_res(tile_pix0, c + 1); younger += 7; }
+                // the next tile's band: its buffer is dead once conv2 is done (behind the T2 barrier); spread over the tail's first positions
+                if (has_next && p >= NCONV && p < NCONV + 4) {
                     if (p == NCONV) decode_band(tile + grid);
-                    const int k = p - NCONV;
-                    issue_band(Sched::band_i0(k), Sched::band_i0(k) + Sched::band_n(k));
+                    const int i0 = 3 * (p - NCONV), i1 = (p == NCONV + 3) ? XPASS : i0 + 3;
+                    issue_band(i0, i1);
+                    younger += i1 - i0;
                 }
-                R50_MARK(0)                       // DMA issue
-                // one wait for the oldest thing the consumers read behind this position's barrier (compile-time counts: Block1LoaderSched)
-                {
-                    constexpr int d_fn = Sched::due(p, true, true), d_fl = Sched::due(p, true, false), d_sn = Sched::due(p, false, true), d_sl = Sched::due(p, false, false);
-                    if (first_tile) {
-                        if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(d_fn > 63 ? 63 : d_fn) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(d_fl > 63 ? 63 : d_fl) : "memory");
-                    } else {
-                        if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(d_sn > 63 ? 63 : d_sn) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(d_sl > 63 ? 63 : d_sl) : "memory");
-                    }
+                const bool st = (p + 2 < SPT) || has_next;
+                if (st) { stage_issue(p + 2 < SPT ? p + 2 : p + 2 - SPT); younger += WPASS; }
+                // out_c(c), complete behind the OUTC barrier, is intact until E(c + 1): copied out one position later (C1N = 64: the A(c + 1)
+                // position; C1N = 128: the second B position), chunk 3 at the tile's last position
+                const bool cpos = (C1N == 64) ? ((r == 0 && c >= 1) || p == SPT - 1) : (r == NA + 1);
+                if (cpos) {
+                    copy_out(tile_pix0, (C1N == 64 && p != SPT - 1) ? c - 1 : c);
+                    younger += 7;
+                    carry = 7;
                 }
-                R50_MARK(1)                       // wait
+                wait_younger(younger);            // stage p + 1 and everything older (identity rows, band passes) landed
                 __builtin_amdgcn_s_barrier();
-                R50_MARK(2)                       // stage barrier
-            });
-            first_tile = false;
+            }
         }
-        R50_STAMP_FLUSH(12)
     } else {
         // =============================== consumer waves =============================================
         const int wave_a = wave & 1, wave_q = wave >> 1;                 // cout group (32 of 64), pixel quarter: blocks 0-3, 4-7, 8-10, 11-13
         const int qb0 = wave_q < 2 ? 4 * wave_q : 8 + 3 * (wave_q - 2);
         const int fr = lane & 15, fq = lane >> 4;
         const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.N * (3136u * C1N * 2u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.N * (3136u * 512u), 0x00020000);
         const int w_row = (wave_a * 32 + fr) * 128;                       // + m * 2048
         const int w_ph0 = (fq ^ (fr & 7)) << 4;                          // kk = 0; kk = 1 is ^ 64
         const int ch_lane = wave_a * 32 + 8 * fq;                        // this lane's 8 consecutive channels of a 64-channel group
@@ -4647,12 +4580,9 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            R50_STAMP_DECL
             auto stage_done = [&]() {             // the barrier stays behind the stage's last fragment read
                 cbuf = (cbuf == NST - 1) ? 0 : cbuf + 1;
-                R50_MARK(0)                       // fragment reads + MFMAs of the stage
                 __builtin_amdgcn_s_barrier();
-                R50_MARK(1)                       // stage barrier
             };
             auto pack_relu = [&](const f32x4& lo, const f32x4& hi) {
                 u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
@@ -4697,13 +4627,9 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
 #pragma unroll
                 for (int h = 0; h < NB1; ++h) set_bias(accB[h], 320 + 64 * h);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                R50_MARK(2)                       // t2 -> LDS, accumulator set-up
                 __builtin_amdgcn_s_barrier();                   // T2 complete
-                R50_MARK(3)
 #pragma unroll 1
                 for (int c = 0; c < 4; ++c) {
-                    int opq2 = 0;                 // (keeps the copy-out's lane constants out of the registers that live across the loops)
-                    asm volatile("" : "+v"(opq2));
                     set_bias(acc, 64 + 64 * c);
                     // ---- A(c): W3[64 c ..] . t2
                     gemm64(smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) { return smem + T2_OFF + ((pb0 + 2048 * (t % NQ)) ^ (t >= NQ ? 64 : 0)); }, acc);
@@ -4734,24 +4660,7 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    R50_MARK(2)                   // E(c)
                     __builtin_amdgcn_s_barrier();               // OUTC(c) complete
-                    R50_MARK(3)
-                    // out_c -> block output (round 4: by the consumer waves): 224 rows x 128 B = 1,792 16-byte pieces over 512 lanes, a row's eight pieces on
-                    // eight consecutive lanes (full 128-B lines); 3.5 ds_read_b128 + 3.5 stores per wave where the four loader waves had 14 + 14 each
-                    // in ONE barrier interval.  Every wave's reads are retired before its stores, i.e. before the barrier behind B(c): E(c + 1) comes later.
-                    {
-                        const unsigned tp = (unsigned)((tile / 14) * 3136 + (tile % 14) * NPX);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int e = i * 512 + tid + opq2;
-                            if (e < NPX * 8) {
-                                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + OUTC_OFF + e * 16);
-                                const int R = e >> 3, sl = e & 7;
-                                __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, ((tp + (unsigned)R) * 256u + (unsigned)(c * 64 + (sl ^ (R & 7)) * 8)) * 2u, 0, 0);
-                            }
-                        }
-                    }
                     // ---- B(c): W1[64 h .., 64 c ..] . out_c into the next conv1's accumulators
 #pragma unroll
                     for (int h = 0; h < NB1; ++h) {
@@ -4759,354 +4668,6 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
                         stage_done();
                     }
                 }
-#pragma unroll
-                for (int h = 0; h < NB1; ++h)
-#pragma unroll
-                    for (int j = 0; j < NQ; ++j) {
-                        const u32x4 o = pack_relu(accB[h][0][j], accB[h][1][j]);
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, ((pix0 + 16 * j) * (unsigned)C1N + (unsigned)(64 * h + ch_lane)) * 2u, 0, 0);
-                    }
-                R50_MARK(4)                       // next t1 -> HBM
-            }
-            R50_STAMP_FLUSH(12)
-        };
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's part of the biases is in LDS ...
-        __builtin_amdgcn_s_barrier();                           // ... and so is everybody's; band + stage 0 landed
-        if (wave_q < 2) run(std::integral_constant<int, 4>{});
-        else run(std::integral_constant<int, 3>{});
-    }
-#else
-    (void)a;
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// bneck_block1f_kernel (round 4): the plain-identity layer1 bodies (layer1.1, layer1.2) with FAT weight stages.
-// What the stamps of bneck_block1_kernel say (profiles/r04_stamps_block1_v3.txt): a consumer wave is busy ~760 cycles per 8-KB stage for the 256
-// cycles its 16 MFMAs take (first-fragment LDS latency, barrier entry / exit) and waits ~510 more at the stage's barrier; a tile is 22 barrier
-// intervals, and the chip holds only ~1.55 GHz under this kernel.  The cost is per INTERVAL, whatever it carries -- so the intervals get fatter:
-//   * the identity no longer passes through LDS: a consumer lane needs exactly the 16 B of its own 8 channels of its own pixel per block, loaded
-//     straight into registers TWO chunks ahead (the consumers issue no LDS-DMA, so hipcc's vmcnt bookkeeping of these loads is exact, and their
-//     queue holds HBM-class operations only: identity loads, copy-out stores, next-t1 stores);
-//   * RESB's 28 KB go to the ring: three stages of 16 KB = TWO [64 rows][64 K] halves each:
-//       conv2: 5 stages = taps (0,1) (2,3) (4,5) (6,7) (8,-)              [was 9]
-//       chunk c, C1N = 64:  ONE stage [W3[64 c ..] | W1[.., 64 c ..]]: A(c), E(c), OUTC barrier, copy-out, B(c), stage barrier      [was 2 stages]
-//       chunk c, C1N = 128: [W3[64 c ..] | W1[0..63, 64 c ..]] then [W1[64..127, 64 c ..] | -]                                          [was 3]
-//     14 barrier intervals per tile for C1N = 64 (22), 18 for C1N = 128 (26);
-//   * the loaders (four uniform waves) carry the weight ring and the next tile's band only, the weight stage first in every iteration so that
-//     nothing of the HBM class stands in front of it in the in-order vmcnt queue (Block1FatSched: the wait counts as a compile-time table);
-//     the copy-out of out_c is done by the consumer waves (3.5 ds_read_b128 + 3.5 full-row stores per wave and chunk).
-// Same summation orders as bneck_block1_kernel: bit-identical outputs.
-// LDS: XB 45,056 | T2 28,672 | OUTC 28,672 | ring 3 x 16,384 | biases 1,792 = 153,344 B.
-// ------------------------------------------------------------------------------------------------
-template <int C1N>
-struct Block1FatSched {
-    static constexpr int NB1 = C1N / 64, NCONV = 5, LCH = NB1, SPT = NCONV + 4 * LCH, XPASS = 11, SDMA = 4;   // SDMA: DMAs per wave and stage (2 halves x 2 passes)
-    // the next tile's band (11 passes) over the chunk positions but the last: C1N = 64: 4 4 3 -; C1N = 128: 2 2 2 2 2 1 - -
-    static constexpr int band_n(int k) { return C1N == 64 ? (k < 2 ? 4 : (k == 2 ? 3 : 0)) : (k < 5 ? 2 : (k == 5 ? 1 : 0)); }
-    static constexpr int band_i0(int k) { return C1N == 64 ? 4 * k : 2 * k; }
-    struct State { int after_stage, after_band; };
-    static constexpr State prologue() { return State{0, SDMA}; }          // issued: stage 0, band, stage 1; (stage 0 + band waited for)
-    static constexpr int run(State st, bool has_next, int p_stop, State* out) {
-        int due = 0;
-        for (int p = 0; p <= p_stop; ++p) {
-            due = st.after_stage;
-            if ((p + 2 < SPT) || has_next) { due += SDMA; st.after_band += SDMA; st.after_stage = 0; }
-            if (has_next && p >= NCONV && band_n(p - NCONV) > 0) {
-                const int n = band_n(p - NCONV);
-                due += n; st.after_stage += n; st.after_band = 0;
-            }
-            if (p == SPT - 1 && has_next && st.after_band < due) due = st.after_band;
-        }
-        if (out) *out = st;
-        return due;
-    }
-    static constexpr State steady() { State e{0, 0}; (void)run(prologue(), true, SPT - 1, &e); return e; }
-    static constexpr int due(int p, bool first_tile, bool has_next) { return run(first_tile ? prologue() : steady(), has_next, p, nullptr); }
-};
-
-template <int ET, int C1N>
-__global__ __launch_bounds__(768) void bneck_block1f_kernel(const Block1Args a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(C1N == 64 || C1N == 128, "next conv1: 256 -> 64 or 256 -> 128");
-    using Sched = Block1FatSched<C1N>;
-    constexpr int IW = 56, TR = 4, PW = IW + 2, PP = (TR + 2) * PW;       // 348 padded positions
-    constexpr int XPASS = (PP + 31) / 32, XBUF = XPASS * 32 * 128;        // 11 passes, 45,056 B
-    constexpr int NPX = TR * IW, SLOT = NPX * 128;                        // 224 rows, 28,672 B
-    constexpr int XB_OFF = 0, T2_OFF = XBUF, OUTC_OFF = T2_OFF + SLOT, RING_OFF = OUTC_OFF + SLOT;
-    constexpr int NST = 3, WHALF = 64 * 128, WSTAGE = 2 * WHALF;
-    constexpr int BIAS_OFF = RING_OFF + NST * WSTAGE;                     // b2 (64) | b3 (256) | b1 (C1N) floats
-    constexpr int NB1 = C1N / 64, NCONV = Sched::NCONV, LCH = Sched::LCH, SPT = Sched::SPT;
-    static_assert(Sched::XPASS == XPASS && BIAS_OFF + 448 * 4 <= 163840, "schedule table = kernel geometry; LDS map");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grid = gridDim.x, first = blockIdx.x;
-
-    if (tid < 64 + 256 + C1N) {
-        float v;
-        if (tid < 64) v = a.b2[tid];
-        else if (tid < 320) v = a.b3[tid - 64];
-        else v = a.b1[tid - 320];
-        reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = v;
-    }
-
-    if (wave >= 8) {
-        // =============================== loader waves: weight ring + the next tile's band ==============
-        const int lw = wave - 8, lt = tid - 512;
-        const int srow = lt >> 3, slot = lt & 7;
-        const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w2), 0, 64u * 576u * 2u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w3), 0, 256u * 64u * 2u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w1), 0, (unsigned)C1N * 256u * 2u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.t1), 0, (unsigned)a.N * (3136u * 128u), 0x00020000);
-        unsigned w2v[2], w3v[2], w1v[2], x_voff[XPASS];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rho = i * 32 + srow;                               // LDS row of a stage half (< 64)
-            const int cl = (rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3);
-            const unsigned ch = (unsigned)((slot ^ (rho & 7)) * 8);
-            w2v[i] = ((unsigned)cl * 576u + ch) * 2u;
-            w3v[i] = ((unsigned)cl * 64u + ch) * 2u;
-            w1v[i] = ((unsigned)cl * 256u + ch) * 2u;
-        }
-        auto decode_band = [&](int tile) {        // source offsets of the padded positions of `tile` (out of range = zero border)
-            const int n = tile / 14, tr = tile - n * 14;
-#pragma unroll
-            for (int i = 0; i < XPASS; ++i) {
-                const int q = i * 32 + srow;
-                const int rr = q / PW, cc = q - rr * PW;
-                const int y = tr * TR + rr - 1, x = cc - 1;
-                const bool ok = q < PP && tile < a.n_tiles && (unsigned)y < 56u && (unsigned)x < 56u;
-                x_voff[i] = ok ? (unsigned)(((n * 56 + y) * 56 + x) * 64 + (slot ^ ((rr * IW + cc) & 7)) * 8) * 2u : kOobOffset;      // (chunk key: see bneck_block2_kernel)
-            }
-        };
-        auto issue_band = [&](int i0, int i1) {   // passes [i0, i1) of the band decoded last
-#pragma unroll
-            for (int i = 0; i < XPASS; ++i)
-                if (i >= i0 && i < i1)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + XB_OFF + i * 4096 + lw * 1024), 16, x_voff[i], 0, 0, 0);
-        };
-        int ring = 0;                             // ring slot of the next stage to issue
-        auto stage_issue = [&](auto p_c) {        // stage P (0 .. SPT-1) of a tile: 4 DMAs per wave (a half that does not exist reads out of range: zeros)
-            constexpr int P = decltype(p_c)::value;
-            char* sbase = smem + RING_OFF + ring * WSTAGE + lw * 1024;
-            ring = (ring == NST - 1) ? 0 : ring + 1;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if constexpr (P < NCONV) {
-                    const int tap = 2 * P + h;
-                    const int sofs = __builtin_amdgcn_readfirstlane(tap * 64 * 2);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (LDS_AS void*)(sbase + h * WHALF + i * 4096), 16, tap < 9 ? w2v[i] : kOobOffset, sofs, 0, 0);
-                } else {
-                    constexpr int q = P - NCONV, c = q / LCH, r = q - c * LCH;
-                    // r == 0: [W3[64 c ..] | W1 half 0, K-slice c];  r == 1 (C1N = 128): [W1 half 1, K-slice c | -]
-                    const bool is_w3 = (r == 0 && h == 0), none = (r == 1 && h == 1);
-                    const int sofs = __builtin_amdgcn_readfirstlane(is_w3 ? c * 64 * 64 * 2 : ((r == 0 ? 0 : 1) * 64 * 256 + c * 64) * 2);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(is_w3 ? rs_w3 : rs_w1, (LDS_AS void*)(sbase + h * WHALF + i * 4096), 16,
-                                                                 none ? kOobOffset : (is_w3 ? w3v[i] : w1v[i]), sofs, 0, 0);
-                }
-            }
-        };
-        // prologue: stage 0, the band, stage 1 -- stage 0 and the band have landed at the first barrier (stage 1 may be in flight)
-        decode_band(first);
-        stage_issue(std::integral_constant<int, 0>{});
-        issue_band(0, XPASS);
-        stage_issue(std::integral_constant<int, 1>{});
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Sched::SDMA) : "memory");       // (bias writes done)
-        __builtin_amdgcn_s_barrier();
-        bool first_tile = true;
-#pragma unroll 1
-        for (int tile = first; tile < a.n_tiles; tile += grid) {
-            const bool has_next = tile + grid < a.n_tiles;
-            static_for<0, SPT>([&](auto p_c) {
-                constexpr int p = decltype(p_c)::value;
-                constexpr int q = p - NCONV, r = q >= 0 ? q % LCH : -1;
-                // 1. the weight stage two positions ahead, first
-                if constexpr (p + 2 < SPT) stage_issue(std::integral_constant<int, p + 2>{});
-                else if (has_next) stage_issue(std::integral_constant<int, p + 2 - SPT>{});
-                // the consumers' extra barriers: T2 complete (in front of the first chunk stage); OUTC(c) complete (in the middle of a chunk's first stage)
-                if constexpr (p == NCONV) __builtin_amdgcn_s_barrier();
-                // 2. a slice of the next tile's band: its buffer is dead once conv2 is done (behind the T2 barrier)
-                if constexpr (q >= 0 && Sched::band_n(q >= 0 ? q : 0) > 0) {
-                    if (has_next) {
-                        if constexpr (q == 0) decode_band(tile + grid);
-                        issue_band(Sched::band_i0(q), Sched::band_i0(q) + Sched::band_n(q));
-                    }
-                }
-                if constexpr (r == 0) __builtin_amdgcn_s_barrier();
-                // 3. stage p + 1 has landed (the next tile's band too, at the last position)
-                {
-                    constexpr int d_fn = Sched::due(p, true, true), d_fl = Sched::due(p, true, false), d_sn = Sched::due(p, false, true), d_sl = Sched::due(p, false, false);
-                    if (first_tile) {
-                        if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(d_fn > 63 ? 63 : d_fn) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(d_fl > 63 ? 63 : d_fl) : "memory");
-                    } else {
-                        if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(d_sn > 63 ? 63 : d_sn) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(d_sl > 63 ? 63 : d_sl) : "memory");
-                    }
-                }
-                __builtin_amdgcn_s_barrier();
-            });
-            first_tile = false;
-        }
-    } else {
-        // =============================== consumer waves =============================================
-        const int wave_a = wave & 1, wave_q = wave >> 1;                 // cout group (32 of 64), pixel quarter: blocks 0-3, 4-7, 8-10, 11-13
-        const int qb0 = wave_q < 2 ? 4 * wave_q : 8 + 3 * (wave_q - 2);
-        const int fr = lane & 15, fq = lane >> 4;
-        const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.N * (3136u * C1N * 2u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.N * (3136u * 512u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.N * (3136u * 512u), 0x00020000);
-        const int w_row = (wave_a * 32 + fr) * 128;                       // + half * 8192 + m * 2048
-        const int w_ph0 = (fq ^ (fr & 7)) << 4;                          // kk = 0; kk = 1 is ^ 64
-        const int ch_lane = wave_a * 32 + 8 * fq;                        // this lane's 8 consecutive channels of a 64-channel group
-        const int p0 = 16 * qb0 + fr, pb0 = p0 * 128 + ((fq ^ (p0 & 7)) << 4), cf_x = wave_a << 6;
-
-        auto run = [&](auto nq_c) {
-            constexpr int NQ = decltype(nq_c)::value;
-            f32x4 acc[2][NQ], accB[NB1][2][NQ];
-            u32x4 idq[4][NQ];                     // identity of chunk c: this lane's 16 B per pixel block, in flight two chunks ahead
-            int cbuf = 0;
-            auto gemm64 = [&](const char* wb, auto xaddr, auto& ac) {
-                constexpr int NS = 2 * NQ, PD = 3;
-                bf16x8 x[NS], wf[2], wg[2];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(wb + m * 2048 + w_ph0);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) wg[m] = *reinterpret_cast<const bf16x8*>(wb + m * 2048 + (w_ph0 ^ 64));
-#pragma unroll
-                for (int t = 0; t < PD; ++t) x[t] = *reinterpret_cast<const bf16x8*>(xaddr(t));
-#pragma unroll
-                for (int t = 0; t < NS; ++t) {
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) ac[m][t % NQ] = mfma_e<ET>(t >= NQ ? wg[m] : wf[m], x[t], ac[m][t % NQ]);
-                    if (t + PD < NS) x[t + PD] = *reinterpret_cast<const bf16x8*>(xaddr(t + PD));
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, 4 + PD, 0);
-#pragma unroll
-                for (int t = 0; t < NS; ++t) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    if (t + PD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            auto stage_done = [&]() {             // the barrier stays behind the stage's last fragment read
-                cbuf = (cbuf == NST - 1) ? 0 : cbuf + 1;
-                __builtin_amdgcn_s_barrier();
-            };
-            auto pack_relu = [&](const f32x4& lo, const f32x4& hi) {
-                u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
-                return o;
-            };
-            auto set_bias = [&](f32x4 (&ac)[2][NQ], int fidx) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (fidx + ch_lane) * 4);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (fidx + ch_lane + 4) * 4);
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) { ac[0][j] = lo; ac[1][j] = hi; }
-            };
-            auto tile_pix = [&](int tile) { return (unsigned)((tile / 14) * 3136 + (tile % 14) * NPX); };
-            auto id_load = [&](auto c_c, int tile, int p0v) {
-                constexpr int C = decltype(c_c)::value;
-                const unsigned pix = tile_pix(tile) + (unsigned)p0v;
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) {
-                    const unsigned voff = tile < a.n_tiles ? ((pix + 16u * j) * 256u + (unsigned)(C * 64 + ch_lane)) * 2u : kOobOffset;
-                    idq[C][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff, 0, 0);
-                }
-            };
-            // chunks the identity loads run ahead: two (C1N = 64); one for C1N = 128, whose second accumulator set of the next conv1 leaves no room for a third identity set
-            constexpr int IDA = (C1N == 128) ? 1 : 2;
-            static_for<0, IDA>([&](auto c_c) { id_load(c_c, first, p0); });
-#pragma unroll 1
-            for (int tile = first; tile < a.n_tiles; tile += grid) {
-                const unsigned tp = tile_pix(tile);
-                // an opaque zero per tile: the lane constants below are recomputed per tile instead of living in registers across the tile loop
-                int opq = 0;
-                asm volatile("" : "+v"(opq));
-                const int p0q = p0 + opq, pb0q = pb0 + opq, tidq = tid + opq;
-                // ---- conv2: bias, then 5 stages of two taps against the resident band
-                set_bias(acc, 0);
-                {
-                    int q0[NQ];
-#pragma unroll
-                    for (int j = 0; j < NQ; ++j) {
-                        const int p = p0q + 16 * j;
-                        const int r = p / IW, c = p - r * IW;
-                        q0[j] = r * PW + c;
-                    }
-#pragma unroll 1
-                    for (int st = 0; st < NCONV; ++st) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int tap = 2 * st + h;
-                            if (tap < 9) {
-                                const int kh = (tap >= 6) ? 2 : (tap >= 3) ? 1 : 0, kw = tap - 3 * kh;
-                                const int sw = (kh * PW + kw) * 128 + ((fq ^ ((p0q + kh * IW + kw) & 7)) << 4);      // tap offset + the tap's chunk key
-                                gemm64(smem + RING_OFF + cbuf * WSTAGE + h * WHALF + w_row, [&](int t) {
-                                    return smem + XB_OFF + q0[t % NQ] * 128 + (t >= NQ ? (sw ^ 64) : sw);
-                                }, acc);
-                            }
-                        }
-                        stage_done();
-                    }
-                }
-                // ---- t2 = relu(acc) -> T2
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) *reinterpret_cast<u32x4*>(smem + T2_OFF + ((pb0q + 2048 * j) ^ cf_x)) = pack_relu(acc[0][j], acc[1][j]);
-#pragma unroll
-                for (int h = 0; h < NB1; ++h) set_bias(accB[h], 320 + 64 * h);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                   // T2 complete
-                static_for<0, 4>([&](auto c_c) {
-                    constexpr int c = decltype(c_c)::value;
-                    const char* const wst = smem + RING_OFF + cbuf * WSTAGE + w_row;
-                    set_bias(acc, 64 + 64 * c);
-                    // ---- A(c): W3[64 c ..] . t2 (first half of the stage)
-                    gemm64(wst, [&](int t) { return smem + T2_OFF + ((pb0q + 2048 * (t % NQ)) ^ (t >= NQ ? 64 : 0)); }, acc);
-                    // ---- E(c): + identity (registers), ReLU, 16 bit -> OUTC: the block output's chunk and the next conv1's K-slice
-#pragma unroll
-                    for (int j = 0; j < NQ; ++j) {
-                        const u32x4 rr = idq[c][j];
-                        f32x4 lo = acc[0][j], hi = acc[1][j];
-                        lo[0] += unpack_lo_e<ET>(rr[0]); lo[1] += unpack_hi_e<ET>(rr[0]);
-                        lo[2] += unpack_lo_e<ET>(rr[1]); lo[3] += unpack_hi_e<ET>(rr[1]);
-                        hi[0] += unpack_lo_e<ET>(rr[2]); hi[1] += unpack_hi_e<ET>(rr[2]);
-                        hi[2] += unpack_lo_e<ET>(rr[3]); hi[3] += unpack_hi_e<ET>(rr[3]);
-                        *reinterpret_cast<u32x4*>(smem + OUTC_OFF + ((pb0q + 2048 * j) ^ cf_x)) = pack_relu(lo, hi);
-                    }
-                    // the identity IDA chunks on (the next tile's for the last ones) starts its way now
-                    __builtin_amdgcn_sched_barrier(0);
-                    id_load(std::integral_constant<int, (c + IDA) & 3>{}, c + IDA < 4 ? tile : tile + grid, p0q);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();               // OUTC(c) complete
-                    // out_c -> block output: 224 rows x 128 B = 1,792 16-byte pieces over the 512 consumer lanes, a row's eight pieces on eight
-                    // consecutive lanes (full 128-B lines).  Every wave's reads are retired before its stores, i.e. before the barrier behind B(c).
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int e = i * 512 + tidq;
-                        if (e < NPX * 8) {
-                            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + OUTC_OFF + e * 16);
-                            const int R = e >> 3, sl = e & 7;
-                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, ((tp + (unsigned)R) * 256u + (unsigned)(c * 64 + (sl ^ (R & 7)) * 8)) * 2u, 0, 0);
-                        }
-                        if (C1N == 128 && i == 1) __builtin_amdgcn_sched_barrier(0);      // (two pieces at a time: the 128-cout form has no registers to spare)
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // ---- B(c): W1[64 h .., 64 c ..] . out_c into the next conv1's accumulators (second half of the stage; C1N = 128: + the first half of the next)
-                    gemm64(wst + WHALF, [&](int t) { return smem + OUTC_OFF + ((pb0q + 2048 * (t % NQ)) ^ (t >= NQ ? 64 : 0)); }, accB[0]);
-                    stage_done();
-                    if constexpr (NB1 == 2) {
-                        gemm64(smem + RING_OFF + cbuf * WSTAGE + w_row, [&](int t) { return smem + OUTC_OFF + ((pb0q + 2048 * (t % NQ)) ^ (t >= NQ ? 64 : 0)); }, accB[1]);
-                        stage_done();
-                    }
-                });
-                const unsigned pix0 = tp + (unsigned)p0q;
 #pragma unroll
                 for (int h = 0; h < NB1; ++h)
 #pragma unroll

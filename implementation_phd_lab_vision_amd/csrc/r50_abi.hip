@@ -967,9 +967,6 @@ hipError_t launch_bneck_block2(const void* t1, int n, const void* w2, const floa
     return hipGetLastError();
 }
 
-// bneck_block1f_kernel (round 4: 16-KB weight stages, identity through the consumers' registers) for the plain-identity layer1 bodies; 0 = bneck_block1_kernel
-// (8-KB stages, identity rows through LDS) for them too.  A/B knob: R50_BLOCK1_FAT / option "block1_fat".  layer1.0 (downsample identity) always runs bneck_block1_kernel.
-int g_block1_fat = [] { const char* v = std::getenv("R50_BLOCK1_FAT"); return v ? std::atoi(v) : 1; }();
 // layer1.1 / .2 bottleneck body in one launch (kernels.h: bneck_block1_kernel): conv2 + conv3 + identity + ReLU + the next conv1 (c1 = 64 or 128)
 hipError_t launch_bneck_block1(const void* t1, int n, const void* w2, const float* b2, const void* w3, const float* b3, const void* res,
                                void* out, const void* w1, int c1, const float* b1, void* y1n, hipStream_t s, int et = 0,
@@ -987,21 +984,9 @@ hipError_t launch_bneck_block1(const void* t1, int n, const void* w2, const floa
     a.t1 = (const __bf16*)t1; a.w2 = (const __bf16*)w2; a.b2 = b2; a.w3 = (const __bf16*)w3; a.b3 = b3; a.res = (const __bf16*)res;
     a.out = (__bf16*)out; a.w1 = (const __bf16*)w1; a.b1 = b1; a.y1n = (__bf16*)y1n; a.N = n; a.n_tiles = 14 * n;
     a.wd = (const __bf16*)wd; a.bd = bd;
-#if defined(R50_STAMP)
-    a.dbg = g_dbg;
-#endif
     const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
     constexpr size_t lds = 11 * 32 * 128 + 3 * 224 * 128 + 3 * 8192 + (448 + 256) * 4;       // 158,464 (kernels.h: LDS map; bd behind b1)
     void (*kern)(const Block1Args);
-    if (!wd && g_block1_fat) {
-        constexpr size_t ldsf = 11 * 32 * 128 + 2 * 224 * 128 + 3 * 16384 + 448 * 4;         // 153,344 (kernels.h: bneck_block1f_kernel's LDS map)
-        if (c1 == 64) kern = et == 1 ? bneck_block1f_kernel<1, 64> : bneck_block1f_kernel<0, 64>;
-        else kern = et == 1 ? bneck_block1f_kernel<1, 128> : bneck_block1f_kernel<0, 128>;
-        hipError_t ef = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
-        if (ef != hipSuccess) return ef;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(768), ldsf, s, a);
-        return hipGetLastError();
-    }
     if (wd) kern = et == 1 ? bneck_block1_kernel<1, 64, true> : bneck_block1_kernel<0, 64, true>;
     else if (c1 == 64) kern = et == 1 ? bneck_block1_kernel<1, 64> : bneck_block1_kernel<0, 64>;
     else kern = et == 1 ? bneck_block1_kernel<1, 128> : bneck_block1_kernel<0, 128>;
@@ -2003,7 +1988,6 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "fuse_block2") h->fuse_block2 = value ? 1 : 0;
     else if (k == "fuse_block1") { if (value < 0 || value > 3) return fail(h, R50_ERR_INVALID, "fuse_block1 must be 0 .. 3"); h->fuse_block1 = (int)value; }
     else if (k == "xres_variant") g_xres_variant = (int)value;        // process-wide A/B knob
-    else if (k == "block1_fat") g_block1_fat = value ? 1 : 0;          // process-wide A/B knob
     else if (k == "use_g8") { if (value < 0 || value > 3) return fail(h, R50_ERR_INVALID, "use_g8 must be 0 .. 3"); g_use_g8 = (int)value; }   // process-wide A/B knob
     else if (k == "use_s2") g_use_s2 = (int)value;                     // process-wide A/B knob: 0 = generic tiles for the stride-2 3x3 shapes
     else if (k == "cu_cap") { if (value < 0 || value > 4096) return fail(h, R50_ERR_INVALID, "cu_cap must be in [0,4096]"); g_cu_cap = (int)value; g_num_cus = 0; }
@@ -2028,7 +2012,6 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "tail3_variant") *value = g_tail3_variant;
     else if (k == "tail3_bp") *value = g_tail3_bp;
     else if (k == "use_g8") *value = g_use_g8;
-    else if (k == "block1_fat") *value = g_block1_fat;
     else if (k == "fuse_cat_chain") *value = h->fuse_cat_chain;
     else if (k == "fuse_tail3_last") *value = h->fuse_tail3_last;
     else if (k == "fuse_fp8_handover") *value = h->fuse_fp8_handover;

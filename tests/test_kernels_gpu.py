@@ -248,38 +248,12 @@ def test_bneck_block2_equals_unfused(lib_built, n, chain):
         assert y1n is None
 
 
-class _process_option:
-    """Sets a process-wide library option (through any handle) for the duration of a test."""
-    def __init__(self, key, value):
-        self.key, self.value = key, value
-
-    def __enter__(self):
-        from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
-        self.bb = ResNet50Backbone(seed=0, max_batch=2).to(_dev())
-        self.old = self.bb.get_option(self.key)
-        self.bb.set_option(self.key, self.value)
-        return self
-
-    def __exit__(self, *exc):
-        self.bb.set_option(self.key, self.old)
-        self.bb.close()
-        return False
-
-
-@pytest.mark.parametrize("fat", [1, 0], ids=["block1f_kernel", "block1_kernel"])
 @pytest.mark.parametrize("c1", [64, 128])
 @pytest.mark.parametrize("n", [1, 3, 20, 41])
-def test_bneck_block1_equals_unfused(lib_built, n, c1, fat):
+def test_bneck_block1_equals_unfused(lib_built, n, c1):
     """Layer1 bottleneck body in one launch: block output and next t1 are the same bits as the resident-weights 3x3 launch followed by
-    the 1x1 igemm launches (n = 20: 280 tiles, more than one per workgroup; n = 41: 574 tiles, up to three per workgroup: the consumers' identity
-    loads of bneck_block1f_kernel run two chunks -- half a tile -- ahead, across tile borders).  fat = 1: bneck_block1f_kernel (16-KB weight
-    stages, identity through registers: the default); 0: bneck_block1_kernel (8-KB stages, identity rows through LDS)."""
+    the 1x1 igemm launches (n = 20: 280 tiles, more than one per workgroup; n = 41: 574 tiles, up to three per workgroup)."""
     from implementation_phd_lab_vision_amd import ops
-    with _process_option("block1_fat", fat):
-        _block1_case(ops, n, c1)
-
-
-def _block1_case(ops, n, c1):
     g = torch.Generator().manual_seed(5100 + n + c1)
     d = _dev()
     t1 = _rand_bf16((n, 56, 56, 64), g).clamp_(min=0).to(d)
