@@ -1337,47 +1337,43 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
 // a tile's input pixels -- with their halo -- are staged into LDS ONCE per 64-channel chunk and all nine taps read them there, so
 // only the weights stream (the generic implicit GEMM re-stages the pixel rows for every tap: 9x the activation traffic from L2 into
 // LDS, which at a CU's ~40 B/clk of L2 feed makes its 128x224 tile feed-bound: 44 KB per 896 MFMA cycles).
-// Tile = 196 output pixels (13 MFMA column blocks) x BC output channels:
-//     14x14 images: one image            (NI = 1, TR = 14)      BC = 256 = all couts:  256 tiles at batch 256 = one full round
-//      7x7  images: four images          (NI = 4, TR = 7)       BC = 128:              64 x 4 = 256 tiles
-//     28x28 images: a band of 7 rows     (NI = 1, TR = 7)       BC = 128 = all couts:  1024 tiles = four rounds
-// LDS: two input buffers [NI panels of (TR+2) x (IW+2) positions][128 B] (zero border by out-of-range DMA; the next chunk's rows are
-// fetched while the current chunk's nine taps run) + a ring of three weight stages [BC rows][128 B].  Rows of 128 B, 16-B chunk c of
-// row r at chunk c ^ (r & 7).  One K-step = one tap of one chunk; the K order is (chunk, tap, channel) -- not the generic kernel's
-// (tap, chunk, channel) -- so sums differ from its in the last fp32 bits; these shapes therefore ALWAYS take this kernel, at every
-// batch size (a frame's features must not depend on the batch it travels in).
-// 8 consumer waves (cout group w & 3, pixel half w >> 2: blocks 0..6 / 7..12; waves w and w + 4 share a SIMD) + 4 loader waves.
+// Tile = 196 output pixels x 128 output channels, held as ROW BLOCKS: the padded row is 16 / 32 positions wide and an MFMA column block is
+// 16 consecutive POSITIONS, 14 blocks per tile, 7 per pixel half:
+//     14x14 images: one image (NI = 1, TR = 14): a 14-pixel image row + 2 unused slots per block       512 tiles at batch 256 = two full rounds
+//     28x28 images: a band of 7 rows (NI = 1, TR = 7): half of a 28-pixel row per block                 1,024 tiles
+//      7x7  images: four images (NI = 4, TR = 7): a row of 16 positions holds the same image row of TWO images with shared zero columns
+//                   (see the kernel's first lines)                                                       256 tiles
+// A fragment address is (lane constant of the tap column and K half) + (block + kernel row) * 2048 + buffer: the K loop carries NO vector-ALU
+// address arithmetic and every ds_read is base + immediate (2 VALU instructions per 28 MFMAs).
+// LDS: two input buffers [padded positions][128 B] (zero border by out-of-range DMA; the next chunk's rows are fetched while the current
+// chunk's nine taps run) + a ring of three weight stages [128 rows][128 B].  16-B chunk c of a position at c ^ (column & 7), of a weight row
+// at c ^ (row & 7).  One K-step = one tap of one chunk; the K order is (chunk, tap, channel) -- not the generic kernel's (tap, chunk, channel)
+// -- so sums differ from its in the last fp32 bits; these shapes therefore ALWAYS take this kernel, at every batch size (a frame's features
+// must not depend on the batch it travels in).
+// 8 consumer waves (cout group w & 3, pixel half w >> 2; waves w and w + 4 share a SIMD) + 4 loader waves on a static schedule (the nine
+// iterations of a chunk unrolled: compile-time pass indices, one scalar compare for the wait).
+// Rounds 2-3 carried eleven more schedules of this kernel -- the 13-block addressing it started with, barriers in mid-step, rings of 4-5 stages,
+// staggered SIMD partners, 256 couts per tile, three taps per step, the 32x32x16 MFMA with four consumer waves -- all bit-identical except the last,
+// all slower or equal (profiles/r03_xres_variants.txt, r02_ablations_conv3x3_xres.txt); round 4 removed them (git history has them).
 // ------------------------------------------------------------------------------------------------
-// Diagnostic ablations (scripts/build_variant.sh -DXRES_ABL=mask; timing only, results are wrong; consumer bits act on SCHED 1 and on RB 1):
+// Diagnostic ablations (scripts/build_variant.sh -DXRES_ABL=mask; timing only, results are wrong):
 // 1 = pixel-fragment addresses without the per-tap arithmetic, 4 = no stores, 8 = no MFMAs (reads stay live), 16 = no pixel-fragment
 // reads, 32 = every LDS-DMA zero-fills (issued, no L2 traffic), 64 = the loaders issue no DMA at all (barriers only), 128 = no per-step barrier,
 // 256 = no weight DMAs (input DMAs stay), 512 = no input DMAs (weight DMAs stay)
 #ifndef XRES_ABL
 #define XRES_ABL 0
 #endif
-#ifndef XRES_STATIC_LOADER    // row-block form: 1 = the unrolled static loader schedule, 0 = the dynamic loader loop (A/B: scripts/build_variant.sh -DXRES_STATIC_LOADER=0)
+#ifndef XRES_STATIC_LOADER    // 1 = the unrolled static loader schedule, 0 = the dynamic loader loop (A/B: scripts/build_variant.sh -DXRES_STATIC_LOADER=0)
 #define XRES_STATIC_LOADER 1
 #endif
-#ifndef XRES_PD           // row-block schedule: pixel fragments read ahead of their MFMAs
+#ifndef XRES_PD           // pixel fragments read ahead of their MFMAs
 #define XRES_PD 3
 #endif
-// RB = 1 ("row blocks", 14x14 and 28x28 only): the padded row is 16 / 32 positions wide and an MFMA column block is 16 consecutive POSITIONS
-// (one 14-pixel image row + 2 unused slots, or half of a 28-pixel row), 14 blocks per tile, 7 per pixel half.  A fragment address is then
-// (lane constant of the tap column and K half) + (block + kernel row) * 2048 + buffer: the K loop carries NO vector-ALU address arithmetic
-// (SCHED 0 spends ~0.85 VALU per MFMA on it; every one of those holds the SIMD's issue port for 4 of an MFMA's 16 cycles), every
-// ds_read is base + immediate, and both pixel halves have 7 blocks (the 13-block split's critical wave has 7 too).  Block b's accumulators
-// are those of the same output pixels as before with the same K order: bit-identical results.
-// RB = 3: row blocks on v_mfma_f32_32x32x16: an MFMA column block is 32 consecutive positions (7 per tile) and FOUR consumer waves -- one per SIMD,
-// 256 registers each -- own 32 couts x all 224 slots (7 accumulators of 16 registers); 4 loader waves as before.  Per K-step a wave issues
-// 28 MFMAs of 32 cycles (the 16x16x32 form: 28 of 16 cycles on each of two waves) and 32 fragment reads: the MFMA holds the issue port for 8
-// of its 32 cycles, so the other instructions of the step have 24 x 28 cycles instead of 8 x 56 to go out in.  W rows and input positions are
-// chunk-swizzled with key (row >> 1) & 7 (32 consecutive rows per ds_read_b128 instead of 16: (parity, chunk) pairs of a lane group stay
-// distinct); the W row order inside a 32-row block puts 16 CONSECUTIVE couts into a lane's 16 accumulator registers (two 16-B stores).
-// The 32-wide MFMA adds its products in another order than the 16-wide one: results differ from RB 0-2 in the last fp32 bits, so a shape that
-// takes this form takes it at every batch size.
-template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST, int SCHED = 0, int RB = 0>
-__global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const ConvArgs a) {
+template <int ET, int NI, int TR, int IW, int IH>
+__global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // the one form that is left of rounds 2-3's schedule variants: 128 couts per tile, one tap per step, three weight stages, row blocks
+    constexpr int BC = 128, TPS = 1, NST = 3, SCHED = 0, RB = 1;
     // RB 1 at 7x7 (NI = 4): a row of 16 positions holds the same image row of TWO images with shared zero columns, [0 | A0..A6 | 0 | B0..B6] (B's right
     // border is the next row's first position), and the two image pairs sit on top of each other with a shared zero row: 17 rows.  An output row
     // (16 slots, 14 of them pixels: the 12.5 % of the 14x14 form) is one block; blocks 0..6 = pair 0, 8..14 = pair 1 (block 7 is the shared
@@ -1610,87 +1606,6 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
         }
         R50_STAMP_FLUSH(12)
         }
-    } else if constexpr (RB == 3) {
-        // =============================== consumer waves, 32-wide blocks ==============================
-        constexpr int NBK = 7, NS = 4 * NBK, PD = XRES_PD + 1;            // 7 blocks of 32 slots; slot t = 7 ks + b of a step; fragments read ahead
-        const int lr = lane & 31, lh = lane >> 5;
-        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
-        int vb[3][4];                                                   // [tap column][K sub-step]: position lr + kw, chunk (2 ks + lh) ^ key
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) vb[kw][ks] = (lr + kw) * 128 + (((2 * ks + lh) ^ (((lr + kw) >> 1) & 7)) << 4);
-        int wv[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wv[ks] = WRING + (wave * 32 + lr) * 128 + (((2 * ks + lh) ^ ((lr >> 1) & 7)) << 4);
-        const int cout_lane = wave * 32 + 16 * lh;                      // this lane's 16 consecutive couts
-        f32x16 acc[NBK];
-        int x_par = 0;
-        __builtin_amdgcn_s_barrier();             // step 0 and the first input chunk landed
-        for (int tile = first; tile < n_tiles; tile += grid) {
-            const int c0 = (tile % nct) * BC;
-            {
-                f32x16 bv;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 4 * q);
-                    bv[4 * q] = t4[0]; bv[4 * q + 1] = t4[1]; bv[4 * q + 2] = t4[2]; bv[4 * q + 3] = t4[3];
-                }
-#pragma unroll
-                for (int b = 0; b < NBK; ++b) acc[b] = bv;
-            }
-            for (int c = 0; c < cch; ++c) {
-                const char* const xc = smem + x_par * XBUF;
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int kh = tap / 3, kw = tap - 3 * kh;
-                    const char* const xk = xc + kh * 2048 * (PW / 16);
-                    const char* const wk = smem + (tap % 3) * WSTAGE;
-                    auto xread = [&](int t) { return *reinterpret_cast<const bf16x8*>(xk + vb[kw][t / NBK] + (t % NBK) * 4096); };
-                    bf16x8 x[NS], wf[4];
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(wk + wv[ks]);
-#pragma unroll
-                    for (int t = 0; t < PD; ++t) x[t] = xread(t);
-#pragma unroll
-                    for (int t = 0; t < NS; ++t) {
-                        acc[t % NBK] = mfma32_e<ET>(wf[t / NBK], x[t], acc[t % NBK]);
-                        if (t + PD < NS) x[t + PD] = xread(t + PD);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4 + PD, 0);
-#pragma unroll
-                    for (int t = 0; t < NS; ++t) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (t + PD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);                  // the barrier stays behind the step's last fragment read
-                    __builtin_amdgcn_s_barrier();
-                }
-                x_par ^= 1;
-            }
-            // ---- epilogue: ReLU, 16-bit, two 16-B stores per valid slot (slot = 32 b + lr = padded row * PW + column)
-            const int pt = tile / nct;
-            const int band = pt % NB, n = pt / NB;
-#pragma unroll
-            for (int b = 0; b < NBK; ++b) {
-                const int sl = 32 * b + lr;
-                const int r = sl / PW, cx = sl - r * PW;
-                const bool ok = cx < IW && n < a.N;
-                const unsigned pix = (unsigned)((n * IH + band * TR + r) * IW + cx);
-                const unsigned voff = ok ? (pix * (unsigned)a.Cout + (unsigned)(c0 + cout_lane)) * 2u : kOobOffset;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const f32x16 v = acc[b];
-                    u32x4 o = (u32x4){pack2_e<ET>(v[8 * hf], v[8 * hf + 1]), pack2_e<ET>(v[8 * hf + 2], v[8 * hf + 3]),
-                                      pack2_e<ET>(v[8 * hf + 4], v[8 * hf + 5]), pack2_e<ET>(v[8 * hf + 6], v[8 * hf + 7])};
-                    if (a.relu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, ok ? voff + 16u * hf : kOobOffset, 0, 0);
-                }
-            }
-        }
     } else {
         // =============================== consumer waves =============================================
         const int wave_c = wave & 3, wave_p = wave >> 2;
@@ -1712,251 +1627,6 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
         }
         f32x4 acc[MR][7];
         int c_buf = 0, x_par = 0;
-        auto run_steps = [&](auto nrw_c) {
-            constexpr int NRW = decltype(nrw_c)::value;                 // 7 blocks (first pixel half) or 6
-            constexpr int PD = 3;                                       // pixel fragments read ahead of their MFMAs
-            R50_STAMP_DECL
-#if defined(R50_STAMP)
-            const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
-            st_sum[5] = clk0 - t_entry;                                 // kernel entry -> first stage landed (prologue)
-#endif
-            for (int tile = first; tile < n_tiles; tile += grid) {
-                const int c0 = (tile % nct) * BC;
-#pragma unroll
-                for (int t = 0; t < MR / 2; ++t) {
-                    const f32x4 b_lo = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t);
-                    const f32x4 b_hi = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t + 4);
-#pragma unroll
-                    for (int j = 0; j < NRW; ++j) { acc[2 * t][j] = b_lo; acc[2 * t + 1][j] = b_hi; }
-                }
-                for (int c = 0; c < cch; ++c) {
-                    const char* xb = smem + x_par * XBUF;
-                    for (int s = 0; s < SPC; ++s) {
-#pragma unroll
-                      for (int tt = 0; tt < TPS; ++tt) {
-                        const int tap = s * TPS + tt;
-                        const int kh = tap / 3, kw = tap - 3 * kh;
-                        const int toff = kh * PW + kw;
-                        const char* wb = smem + WRING + c_buf * WSTAGE + tt * (BC * 128) + w_row;
-                        // 2 x NRW slots t = NRW kk + j: one pixel fragment, MR MFMAs; the fragment of slot t + PD is read when slot t issues
-                        // chunk key of this tap: (pixel index + kh * IW + kw) & 7, the same for every block of the lane (16 j = 0 mod 8)
-                        const int sw = toff * 128 + ((fq ^ ((p_lane + kh * IW + kw) & 7)) << 4);
-                        auto xread = [&](int t) {
-                            return *reinterpret_cast<const bf16x8*>(xb + q0[t % NRW] * 128 + (t >= NRW ? (sw ^ 64) : sw));
-                        };
-                        // order pinned with sched_group_barrier: hoisted by the compiler, the reads of a whole step (three taps) are live at once
-                        constexpr bool W2 = (MR <= 2);                  // both K halves' weight fragments up front (registers permitting)
-                        bf16x8 x[2 * NRW], wf[MR], wg[W2 ? MR : 1];
-#pragma unroll
-                        for (int m = 0; m < MR; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(wb + m * 2048 + w_ph0);
-                        if constexpr (W2) {
-#pragma unroll
-                            for (int m = 0; m < MR; ++m) wg[m] = *reinterpret_cast<const bf16x8*>(wb + m * 2048 + (w_ph0 ^ 64));
-                        }
-#pragma unroll
-                        for (int t = 0; t < PD; ++t) x[t] = xread(t);
-#pragma unroll
-                        for (int t = 0; t < 2 * NRW; ++t) {
-                            if constexpr (!W2) {
-                                if (t == NRW) {
-#pragma unroll
-                                    for (int m = 0; m < MR; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(wb + m * 2048 + (w_ph0 ^ 64));
-                                }
-                            }
-#pragma unroll
-                            for (int m = 0; m < MR; ++m) acc[m][t % NRW] = mfma_e<ET>((W2 && t >= NRW) ? wg[m] : wf[m], x[t], acc[m][t % NRW]);
-                            if (t + PD < 2 * NRW) x[t + PD] = xread(t + PD);
-                        }
-                        __builtin_amdgcn_sched_group_barrier(0x100, (W2 ? 2 * MR : MR) + PD, 0);
-#pragma unroll
-                        for (int t = 0; t < 2 * NRW; ++t) {
-                            if (!W2 && t == NRW) __builtin_amdgcn_sched_group_barrier(0x100, MR, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);
-                            if (t + PD < 2 * NRW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-                      }
-                        c_buf = (c_buf == NSTAGE - 1) ? 0 : c_buf + 1;
-#if defined(R50_STAMP)
-                        __builtin_amdgcn_sched_barrier(0);
-                        asm volatile("s_nop 0" ::"v"(acc[MR - 1][NRW - 1]), "v"(acc[0][NRW - 1]) : "memory");   // the stamp waits for the last MFMAs
-#endif
-                        R50_MARK(1)                                     // fragment reads + MFMAs
-                        __builtin_amdgcn_sched_barrier(0);              // the barrier stays behind the step's last fragment read
-                        __builtin_amdgcn_s_barrier();
-                        R50_MARK(2)                                     // barrier
-                    }
-                    x_par ^= 1;
-                }
-                R50_MARK(0)                                             // (tile begin of the next tile lands here too)
-                // ---- epilogue: ReLU, 16-bit, one 16-B store per pixel and block pair
-                const int pt = tile / nct;
-                const int band = pt % NB, n0 = (pt / NB) * NI;
-#pragma unroll
-                for (int j = 0; j < NRW; ++j) {
-                    const int p = 16 * (7 * wave_p + j) + fr;
-                    const int pc = p < NPX ? p : NPX - 1;
-                    const int panel = pc / (TR * IW), rem = pc - panel * (TR * IW);
-                    const int r = rem / IW, cx = rem - r * IW;
-                    const int n = n0 + panel;
-                    const bool ok = p < NPX && n < a.N;
-                    const unsigned pix = (unsigned)((n * IH + band * TR + r) * IW + cx);
-#pragma unroll
-                    for (int t = 0; t < MR / 2; ++t) {
-                        const f32x4 lo = acc[2 * t][j], hi = acc[2 * t + 1][j];
-                        u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
-                        if (a.relu) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
-                        }
-                        const unsigned voff = ok ? (pix * (unsigned)a.Cout + (unsigned)(c0 + cout_lane + 32 * t)) * 2u : kOobOffset;
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff, 0, 0);
-                    }
-                }
-                R50_MARK(3)                                             // epilogue
-            }
-#if defined(R50_STAMP)
-            st_sum[6] = __builtin_readcyclecounter() - clk0;            // shader cycles and 100-MHz ticks of the whole loop: the clock the chip held
-            st_sum[7] = __builtin_amdgcn_s_memrealtime() - rt0;
-#endif
-            R50_STAMP_FLUSH(12)
-        };
-        // SCHED 1: the step's barrier sits in the MIDDLE of the step, and the LDS reads a step starts with -- its weight fragments and its
-        // first PD pixel fragments -- are issued behind the barrier of the step BEFORE it (which is what guarantees that stage has landed),
-        // under that step's remaining MFMAs.  In the schedule above every wave leaves the barrier with nothing in registers: all eight
-        // consumers burst 7 reads each into the LDS at once and every SIMD idles for one loaded LDS round trip (~250 cycles of a
-        // ~1,700-cycle step), then idles again at the step's end while the slowest wave and the loaders arrive.  Here a step's first MFMA
-        // issues straight after the previous step's last one, and a wave that waits at the barrier still has half a step of MFMAs queued
-        // behind it.  Same MFMA order per accumulator: bit-identical results.
-        auto run_steps_mid = [&](auto nrw_c) {
-            constexpr int NRW = decltype(nrw_c)::value, NS = 2 * NRW, PD = 3;
-            constexpr int NXT = 2 * MR + PD;                            // reads of the next step issued behind the barrier
-            constexpr int TB = NS - NXT;                                // slots in front of the barrier
-            static_assert(TPS == 1 && MR <= 2 && TB >= 1 && TB + PD <= NS, "mid-step barrier: one tap per step, both K halves of the weights in registers");
-            int tile = first, c = 0, s = 0, c_buf = 0, x_par = 0;
-            bf16x8 wA[2 * MR], xA[PD], wB[2 * MR], xB[PD];
-            int qa[7];
-#pragma unroll
-            for (int j = 0; j < 7; ++j) qa[j] = q0[j] * 128 + ((fq ^ (q0[j] & 7)) << 4);
-            // `sw` = toff * 128 + ((fq ^ key) << 4) with the tap's chunk key (p_lane + kh * IW + kw) & 7 (see the loader)
-            auto xread = [&](const char* xb, int sw, int t) {
-                if constexpr (XRES_ABL & 16) { return __builtin_bit_cast(bf16x8, (u32x4){(unsigned)sw, 1u, 2u, (unsigned)t}); }
-                else if constexpr (XRES_ABL & 1) { return *reinterpret_cast<const bf16x8*>(xb + (qa[t % NRW] ^ (t >= NRW ? 64 : 0))); }
-                else { return *reinterpret_cast<const bf16x8*>(xb + q0[t % NRW] * 128 + (t >= NRW ? (sw ^ 64) : sw)); }
-            };
-            auto wread = [&](const char* wb, int i) {                   // i < MR: K half 0 of cout block i; else K half 1 of block i - MR
-                return *reinterpret_cast<const bf16x8*>(wb + (i % MR) * 2048 + (i < MR ? w_ph0 : (w_ph0 ^ 64)));
-            };
-            auto init_acc = [&](int tile) {
-                const int c0 = (tile % nct) * BC;
-#pragma unroll
-                for (int t = 0; t < MR / 2; ++t) {
-                    const f32x4 b_lo = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t);
-                    const f32x4 b_hi = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t + 4);
-#pragma unroll
-                    for (int j = 0; j < NRW; ++j) { acc[2 * t][j] = b_lo; acc[2 * t + 1][j] = b_hi; }
-                }
-            };
-            auto epilogue = [&](int tile) {       // ReLU, 16-bit, one 16-B store per pixel and block pair
-                const int c0 = (tile % nct) * BC;
-                const int pt = tile / nct;
-                const int band = pt % NB, n0 = (pt / NB) * NI;
-#pragma unroll
-                for (int j = 0; j < NRW; ++j) {
-                    const int p = 16 * (7 * wave_p + j) + fr;
-                    const int pc = p < NPX ? p : NPX - 1;
-                    const int panel = pc / (TR * IW), rem = pc - panel * (TR * IW);
-                    const int r = rem / IW, cx = rem - r * IW;
-                    const int n = n0 + panel;
-                    const bool ok = p < NPX && n < a.N;
-                    const unsigned pix = (unsigned)((n * IH + band * TR + r) * IW + cx);
-#pragma unroll
-                    for (int t = 0; t < MR / 2; ++t) {
-                        const f32x4 lo = acc[2 * t][j], hi = acc[2 * t + 1][j];
-                        u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
-                        if (a.relu) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
-                        }
-                        const unsigned voff = ok ? (pix * (unsigned)a.Cout + (unsigned)(c0 + cout_lane + 32 * t)) * 2u : kOobOffset;
-                        if (!(XRES_ABL & 4) || o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff, 0, 0);
-                    }
-                }
-            };
-            // operands of step 0 (stage 0 and the first input chunk landed: the barrier in front of this call)
-            {
-                const char* wb = smem + WRING + w_row;
-#pragma unroll
-                for (int i = 0; i < 2 * MR; ++i) wA[i] = wread(wb, i);
-#pragma unroll
-                for (int t = 0; t < PD; ++t) xA[t] = xread(smem, (fq ^ (p_lane & 7)) << 4, t);
-            }
-            init_acc(tile);
-            auto step = [&](bf16x8 (&wc)[2 * MR], bf16x8 (&xc)[PD], bf16x8 (&wn)[2 * MR], bf16x8 (&xn)[PD]) {
-                const int kh = (s >= 6) ? 2 : (s >= 3) ? 1 : 0, kw = s - 3 * kh;
-                const int toff = (kh * PW + kw) * 128 + ((fq ^ ((p_lane + kh * IW + kw) & 7)) << 4);     // (with the tap's chunk key)
-                const char* xb = smem + x_par * XBUF;
-                int ns = s + 1, nx_par = x_par;
-                if (ns == SPC) { ns = 0; nx_par ^= 1; }
-                const int nkh = (ns >= 6) ? 2 : (ns >= 3) ? 1 : 0, nkw = ns - 3 * nkh;
-                const int ntoff = (nkh * PW + nkw) * 128 + ((fq ^ ((p_lane + nkh * IW + nkw) & 7)) << 4);
-                const int nc_buf = (c_buf == NSTAGE - 1) ? 0 : c_buf + 1;
-                const char* nxb = smem + nx_par * XBUF;
-                const char* nwb = smem + WRING + nc_buf * WSTAGE + w_row;
-                bf16x8 x[NS];
-#pragma unroll
-                for (int t = 0; t < PD; ++t) x[t] = xc[t];
-                // ---- slots in front of the barrier
-#pragma unroll
-                for (int t = 0; t < TB; ++t) {
-#pragma unroll
-                    for (int m = 0; m < MR; ++m) {
-                        if constexpr (XRES_ABL & 8) { asm volatile("" ::"v"(t >= NRW ? wc[MR + m] : wc[m]), "v"(x[t])); }
-                        else acc[m][t % NRW] = mfma_e<ET>(t >= NRW ? wc[MR + m] : wc[m], x[t], acc[m][t % NRW]);
-                    }
-                    x[t + PD] = xread(xb, toff, t + PD);
-                }
-#pragma unroll
-                for (int t = 0; t < TB; ++t) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(XRES_ABL & 128)) __builtin_amdgcn_s_barrier();    // the NEXT step's stage has landed; nobody reads the stage before this one any more
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- slots behind it, each with one read of the next step's operands
-#pragma unroll
-                for (int t = TB; t < NS; ++t) {
-#pragma unroll
-                    for (int m = 0; m < MR; ++m) {
-                        if constexpr (XRES_ABL & 8) { asm volatile("" ::"v"(t >= NRW ? wc[MR + m] : wc[m]), "v"(x[t])); }
-                        else acc[m][t % NRW] = mfma_e<ET>(t >= NRW ? wc[MR + m] : wc[m], x[t], acc[m][t % NRW]);
-                    }
-                    if (t + PD < NS) x[t + PD] = xread(xb, toff, t + PD);
-                    const int r = t - TB;
-                    if (r < 2 * MR) wn[r] = wread(nwb, r);
-                    else xn[r - 2 * MR] = xread(nxb, ntoff, r - 2 * MR);
-                }
-#pragma unroll
-                for (int t = TB; t < NS; ++t) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);
-                    if (t + PD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- advance the stream position
-                c_buf = nc_buf; s = ns; x_par = nx_par;
-                if (ns == 0 && ++c == cch) {
-                    c = 0;
-                    epilogue(tile);
-                    tile += grid;
-                    if (tile < n_tiles) init_acc(tile);
-                }
-            };
-            for (int g = 0; g < total; g += 2) {
-                step(wA, xA, wB, xB);
-                if (g + 1 < total) step(wB, xB, wA, xA);
-            }
-        };
         // RB: see the kernel's head.  Ring slot of tap s is s % 3 (nine steps per chunk, three stages), so with the nine taps unrolled every LDS
         // address of the K loop is a lane constant + an immediate.
         auto run_steps_rb = [&]() {
@@ -2056,137 +1726,8 @@ __global__ __launch_bounds__(RB == 3 ? 512 : 768) void conv3x3_xres_kernel(const
                 }
             }
         };
-        // RB 2: row blocks + the barrier in the MIDDLE of the step (SCHED 1's idea with static addresses): behind the barrier of step g -- which
-        // says that stage g + 1 has landed -- every remaining slot of step g carries one read of step g + 1's operands (4 weight fragments, the
-        // first PD pixel fragments), so a step opens with its operands in registers instead of with eight waves bursting 7 reads each into the
-        // LDS and every SIMD idling for that loaded round trip.  Hazards as SCHED 1 (weights of step g are in registers when its barrier is
-        // passed; the loaders refill an input buffer one step later, XS0).  Same MFMA order per accumulator: bit-identical results.
-        auto run_steps_rbm = [&](auto) {
-            constexpr int NRW = 7, NS = 2 * NRW, PD = 3, NXT = 2 * MR + PD, TB = NS - NXT;
-            static_assert(MR == 2 && TB >= 1, "mid-step barrier: 128 couts per tile");
-            const char* const xl = smem + 7 * 2048 * wave_p;
-            int vb[3][2];
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) vb[kw][kk] = (fr + kw) * 128 + (((fq + 4 * kk) ^ ((fr + kw) & 7)) << 4);
-            const char* const wl0 = smem + WRING + w_row + w_ph0;
-            const char* const wl1 = smem + WRING + w_row + (w_ph0 ^ 64);
-            int x_par = 0;
-            bf16x8 wc[2 * MR], xc[PD];
-            // operands of step 0 (stage 0 and the first input chunk landed: the barrier in front of this call)
-#pragma unroll
-            for (int i = 0; i < 2 * MR; ++i) wc[i] = *reinterpret_cast<const bf16x8*>((i < MR ? wl0 : wl1) + (i % MR) * 2048);
-#pragma unroll
-            for (int t = 0; t < PD; ++t) xc[t] = *reinterpret_cast<const bf16x8*>(xl + vb[0][0] + t * 2048);
-            for (int tile = first; tile < n_tiles; tile += grid) {
-                const int c0 = (tile % nct) * BC;
-#pragma unroll
-                for (int t = 0; t < MR / 2; ++t) {
-                    const f32x4 b_lo = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t);
-                    const f32x4 b_hi = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t + 4);
-#pragma unroll
-                    for (int j = 0; j < NRW; ++j) { acc[2 * t][j] = b_lo; acc[2 * t + 1][j] = b_hi; }
-                }
-                for (int c = 0; c < cch; ++c) {
-                    const char* const xc0 = xl + x_par * XBUF;
-                    const char* const xn0 = xl + (x_par ^ 1) * XBUF;
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
-                        const int kh = tap / 3, kw = tap - 3 * kh;
-                        const int ntap = tap == 8 ? 0 : tap + 1, nkh = ntap / 3, nkw = ntap - 3 * nkh;
-                        const char* const x0 = xc0 + vb[kw][0] + kh * 2048 * (PW / 16);
-                        const char* const x1 = xc0 + vb[kw][1] + kh * 2048 * (PW / 16);
-                        const char* const nx0 = (tap == 8 ? xn0 : xc0) + vb[nkw][0] + nkh * 2048 * (PW / 16);
-                        const char* const nw0 = wl0 + (ntap % 3) * WSTAGE;
-                        const char* const nw1 = wl1 + (ntap % 3) * WSTAGE;
-                        auto xread = [&](int t) { return *reinterpret_cast<const bf16x8*>((t >= NRW ? x1 : x0) + (t % NRW) * 2048); };
-                        bf16x8 x[NS], wn[2 * MR], xn[PD];
-#pragma unroll
-                        for (int t = 0; t < PD; ++t) x[t] = xc[t];
-                        // ---- slots in front of the barrier
-#pragma unroll
-                        for (int t = 0; t < TB; ++t) {
-#pragma unroll
-                            for (int m = 0; m < MR; ++m) acc[m][t % NRW] = mfma_e<ET>(t >= NRW ? wc[MR + m] : wc[m], x[t], acc[m][t % NRW]);
-                            x[t + PD] = xread(t + PD);
-                        }
-#pragma unroll
-                        for (int t = 0; t < TB; ++t) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        __builtin_amdgcn_s_barrier();                   // the NEXT step's stage has landed; nobody reads the stage before this one any more
-                        __builtin_amdgcn_sched_barrier(0);
-                        // ---- slots behind it, each with one read of the next step's operands
-#pragma unroll
-                        for (int t = TB; t < NS; ++t) {
-#pragma unroll
-                            for (int m = 0; m < MR; ++m) acc[m][t % NRW] = mfma_e<ET>(t >= NRW ? wc[MR + m] : wc[m], x[t], acc[m][t % NRW]);
-                            if (t + PD < NS) x[t + PD] = xread(t + PD);
-                            const int r = t - TB;
-                            if (r < 2 * MR) wn[r] = *reinterpret_cast<const bf16x8*>((r < MR ? nw0 : nw1) + (r % MR) * 2048);
-                            else xn[r - 2 * MR] = *reinterpret_cast<const bf16x8*>(nx0 + (r - 2 * MR) * 2048);
-                        }
-#pragma unroll
-                        for (int t = TB; t < NS; ++t) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);
-                            if (t + PD < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                            else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int i = 0; i < 2 * MR; ++i) wc[i] = wn[i];
-#pragma unroll
-                        for (int t = 0; t < PD; ++t) xc[t] = xn[t];
-                    }
-                    x_par ^= 1;
-                }
-                // ---- epilogue (as RB 1)
-                const int pt = tile / nct;
-                const int band = pt % NB, n = pt / NB;
-#pragma unroll
-                for (int j = 0; j < NRW; ++j) {
-                    const int sl = 16 * (7 * wave_p + j) + fr;
-                    const int r = sl / PW, cx = sl - r * PW;
-                    const bool ok = cx < IW && n < a.N;
-                    const unsigned pix = (unsigned)((n * IH + band * TR + r) * IW + cx);
-#pragma unroll
-                    for (int t = 0; t < MR / 2; ++t) {
-                        const f32x4 lo = acc[2 * t][j], hi = acc[2 * t + 1][j];
-                        u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
-                        if (a.relu) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
-                        }
-                        const unsigned voff = ok ? (pix * (unsigned)a.Cout + (unsigned)(c0 + cout_lane + 32 * t)) * 2u : kOobOffset;
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff, 0, 0);
-                    }
-                }
-            }
-        };
         __builtin_amdgcn_s_barrier();             // step 0 and the first input chunk landed
-        if constexpr (RB == 2) {
-            run_steps_rbm(0);
-        } else if constexpr (RB == 1) {
-            run_steps_rb();
-        } else if constexpr (SCHED == 1) {
-            if (wave_p == 0) run_steps_mid(std::integral_constant<int, 7>{});
-            else run_steps_mid(std::integral_constant<int, 6>{});
-        } else if constexpr (SCHED == 2) {
-            // STAGGER: the two consumer waves of a SIMD (w and w + 4) run half a step apart.  Waves 0-3 keep the barrier at the END of a step,
-            // waves 4-7 take the mid-step schedule: they meet waves 0-3 at every barrier while they are in the MIDDLE of the same step, so
-            // one wave's fragment-read burst and barrier wait fall under its SIMD partner's MFMAs instead of beside the partner's own
-            // (MI355X_MICROARCH.md, Two waves per SIMD, item 9).  Hazards: a mid-step wave holds step g's weight fragments in registers when
-            // it passes barrier g, so stage g's ring slot is free for the loaders exactly as in SCHED 0; the input buffers follow SCHED 1's
-            // timing (XS0 above).  Same MFMA order per accumulator: bit-identical results.
-            if (wave_p == 0) run_steps(std::integral_constant<int, 7>{});
-            else run_steps_mid(std::integral_constant<int, 6>{});
-        } else {
-            if (wave_p == 0) run_steps(std::integral_constant<int, 7>{});
-            else run_steps(std::integral_constant<int, 6>{});
-        }
+        run_steps_rb();
     }
 #else
     (void)a;
@@ -2840,20 +2381,10 @@ __global__ __launch_bounds__(512) void bneck_tail2_kernel(const Tail2Args a) {
 //     B(c):  accB[256 x P] += W1[:, c] . out_c           2 K-slots x 2 cout halves; accB stays in registers across the 8 chunks
 // and, after chunk 7, y1n = relu(accB) (accB started at b1).  Summation orders are those of the igemm launches this replaces (bias
 // first, K ascending, residual last, the residual added with the same fp32 additions), so both outputs are bit-identical to them.
-// Three roles (what two earlier versions taught: with weights and activations both streaming through one LDS ring under a barrier
-// per K-step, ring issue, L2 latency, fragment reads, MFMAs, epilogue and stores simply ADD UP -- 84 us for 2 x 14.5 us of MFMA):
-//   * 4 CONSUMER waves (wave w: couts 32w.. of every 128-row weight slice, all P = 112 pixel columns = 7 MFMA blocks).  A wave's
-//     weight fragments are private to it, so they do not go through LDS at all: the host-side packing (tail3_pack_kernel) stores every
-//     (chunk, step, wave) slice in MFMA fragment order and the wave fetches it with four fully coalesced 1-KB loads, two steps ahead
-//     into the registers the previous step has just released.  The 64 weight steps of a tile need NO barrier.  Consumers touch
-//     vector memory only for those loads (and the tile's y1n stores): no store ever sits in front of a load in their in-order queue.
-//   * 4 HELPER waves: LDS-DMA of the tile's t2 rows (once per tile) and of each chunk's residual rows (two chunks ahead, double
-//     buffered), and the COPY-OUT of out_c to the block output in HBM with full-row 16-B stores.
-//   * 2 barriers per chunk -- R(c): residual(c) has landed / everybody is done with out_c(c-1); O(c): out_c(c) is complete / res
-//     buffer c&1 is free -- and one per tile (T: t2 rows landed).  17 per tile.
-// P = 112 rows in LDS of which the first `bp` are real (bp = 98 at batch 256: 512 tiles = two full rounds of 256 CUs).
-// LDS (rows of 128 B, 16-B chunk c of row r at chunk c ^ (r & 7) as in the igemm kernels): T2 [4 slots][112] 56 KB, res 2 x [2][112]
-// 56 KB, out_c [2][112] 28 KB, b1 + b3 5 KB = 148,480 B.
+// Rounds 2-3 ran this as bneck_tail3_kernel (4 consumer waves with the weights straight from L2 in fragment order + 4 helper waves for the
+// LDS-DMA of t2 / residual rows and the copy-out; 17 barriers per tile; 82-85 us per launch); round 3's two-group pipeline below
+// (bneck_tail3p_kernel, 71 us) replaced it and the old kernel was removed in round 4 (git history, profiles/r03_tail3p_variants.txt).
+// P = 112 rows in LDS of which the first `bp` are real.
 // ------------------------------------------------------------------------------------------------
 struct Tail3Args {
     const __bf16* y2;     // (M, 256)   conv2 output
@@ -2872,7 +2403,7 @@ struct Tail3Args {
 #endif
 };
 
-// (1024,256) conv3 and (256,1024) next-conv1 weights, K contiguous -> the fragment-ordered stream bneck_tail3_kernel reads.
+// (1024,256) conv3 and (256,1024) next-conv1 weights, K contiguous -> the fragment-ordered stream bneck_tail3p_kernel reads.
 // Element (c, s, w, f = 2m + kk, lane = 16 fq + fr) is the A fragment of row rho = 32w + 16m + fr of the step's 128-row slice, whose
 // channel is perm(rho) (8 consecutive couts per lane, see igemm_bf16_kernel), K = 32 kk + 8 fq .. + 7 of the step's 64.
 __global__ void tail3_pack_kernel(const __bf16* __restrict__ w3, const __bf16* __restrict__ w1, __bf16* __restrict__ wp) {
@@ -2889,319 +2420,6 @@ __global__ void tail3_pack_kernel(const __bf16* __restrict__ w3, const __bf16* _
         src = w1 + (size_t)(hh * 128 + cl) * 1024 + c * 128 + kb * 64 + kk * 32 + fq * 8;
     }
     reinterpret_cast<u32x4*>(wp)[idx] = *reinterpret_cast<const u32x4*>(src);
-}
-
-// Diagnostic ablations of bneck_tail3_kernel (scripts/build_variant.sh -DT3_ABL=mask; timing only, results are wrong):
-// 1 = every LDS-DMA zero-fills (no L2 traffic for t2 / residual), 2 = no HBM stores, 4 = no MFMAs (fragment reads stay),
-// 8 = no residual / epilogue work, 16 = no weight loads
-#ifndef T3_ABL
-#define T3_ABL 0
-#endif
-#ifndef T3_PDA            // LDS prefetch depth (fragment slots) of the A / B weight steps
-#define T3_PDA 4
-#endif
-#ifndef T3_PDB
-#define T3_PDB 7
-#endif
-#ifndef T3_XPRE           // cross-step prefetch of the first pixel fragments, bit mask: 1 = A0..A3, 2 = B0..B3, 4 = B3 -> next chunk's A0 (0 = every step opens with its own reads)
-#define T3_XPRE 0
-#endif
-template <int ET>
-__global__ __launch_bounds__(512) void bneck_tail3_kernel(const Tail3Args a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int CMID = 256, COUT = 1024, C1N = 256;
-    constexpr int NCH = COUT / 128;               // chunks of 128 block-output channels
-    constexpr int PR = 112, NR = 7;               // pixel rows held in LDS / MFMA column blocks
-    constexpr int SLOT = PR * 128;                // one K-slot (64 channels) of PR pixel rows: 14 KB
-    constexpr int T2 = 0, RES = 4 * SLOT, OUTC = RES + 4 * SLOT, B1_OFF = OUTC + 2 * SLOT, B3_OFF = B1_OFF + C1N * 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grid = gridDim.x;
-    const int first = blockIdx.x;
-
-    if (tid < C1N) {                              // both bias vectors live in LDS
-        reinterpret_cast<float*>(smem + B1_OFF)[tid] = a.b1[tid];
-        reinterpret_cast<f32x4*>(smem + B3_OFF)[tid] = reinterpret_cast<const f32x4*>(a.b3)[tid];
-    }
-
-    if (wave >= 4) {
-        // =============================== helper waves: DMA in, copy out ==============================
-        const int lw = wave - 4;
-        const int lt = tid - 256;
-        const int srow = lt >> 3;                  // 0..31: row of a 32-row pass
-        const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.y2), 0, (unsigned)a.M * (CMID * 2u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.M * (COUT * 2u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.M * (COUT * 2u), 0x00020000);
-        // row R = 32 i + srow of a [slots][112]-row region: K-slot R / 112, pixel row R % 112; logical 16-B chunk (lane & 7) ^ (pixel row & 7)
-        // byte offset of the lane's 16 B inside its pixel's channel vector (+ pixel * channels * 2), or out of range
-        auto row_voff = [&](int i, int p0, int limit, int cstride) -> unsigned {
-            const int R = 32 * i + srow;
-            const int sl = (R >= 336) ? 3 : (R >= 224) ? 2 : (R >= 112) ? 1 : 0;
-            const int prow = R - 112 * sl;
-            const int lchunk = (lt & 7) ^ (prow & 7);
-            return (prow < limit && !(T3_ABL & 1)) ? (unsigned)((p0 + prow) * cstride + sl * 64 + lchunk * 8) * 2u : kOobOffset;
-        };
-        auto issue_t2 = [&](int tile) {           // 14 DMAs per wave: the tile's t2 rows, 4 K-slots
-            const int p0 = tile * a.bp;
-            const int limit = (tile < a.n_tiles) ? ((a.M - p0 < a.bp) ? a.M - p0 : a.bp) : 0;
-#pragma unroll
-            for (int i = 0; i < 14; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y2, (LDS_AS void*)(smem + T2 + i * 4096 + lw * 1024), 16, row_voff(i, p0, limit, CMID), 0, 0, 0);
-        };
-        // (round 3) the 7 row offsets of the identity rows / block-output rows of a tile are computed ONCE per tile (this tile's and the next one's)
-        // instead of per DMA and per store: ~110 vector-ALU instructions per chunk and helper wave less on the SIMDs the consumers' MFMAs issue on
-        unsigned rv_cur[7], rv_nxt[7];
-        auto tile_rows = [&](int tile, unsigned (&rv)[7]) {
-            const int p0 = tile * a.bp;
-            const int limit = (tile < a.n_tiles) ? ((a.M - p0 < a.bp) ? a.M - p0 : a.bp) : 0;
-#pragma unroll
-            for (int i = 0; i < 7; ++i) rv[i] = row_voff(i, p0, limit, COUT);
-        };
-        auto issue_res = [&](const unsigned (&rv)[7], int c) {   // 7 DMAs per wave: residual rows of chunk c (2 K-slots) into buffer c & 1
-            const int cofs = __builtin_amdgcn_readfirstlane(c * 256);
-            char* dst = smem + RES + (c & 1) * 2 * SLOT + lw * 1024;
-#pragma unroll
-            for (int i = 0; i < 7; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(dst + i * 4096), 16, rv[i], cofs, 0, 0);
-        };
-        auto copy_out = [&](int tile, int c) {    // 7 x (16 B from out_c -> block output): full 128-B row pieces
-            const int p0 = tile * a.bp;
-            const int limit = (a.M - p0 < a.bp) ? a.M - p0 : a.bp;
-            const int cofs = __builtin_amdgcn_readfirstlane(c * 256);
-            u32x4 v[7];
-#pragma unroll
-            for (int i = 0; i < 7; ++i) v[i] = *reinterpret_cast<const u32x4*>(smem + OUTC + i * 4096 + lt * 16);
-#pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                unsigned voff = rv_cur[i];
-                if (T3_ABL & 1) {                  // (ablation 1 makes row_voff out of range: rebuild the store offset)
-                    const int R = 32 * i + srow, sl = (R >= 112) ? 1 : 0, prow = R - 112 * sl;
-                    voff = (prow < limit) ? (unsigned)((p0 + prow) * COUT + sl * 64 + (((lt & 7) ^ (prow & 7)) * 8)) * 2u : kOobOffset;
-                }
-                if (!(T3_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, voff, cofs, 0);
-            }
-        };
-        // Every wave's vector-memory queue holds, in issue order:  ... Res(t,0) | stores(6) | T2(t) | Res(t,1) | stores(7) |   <- previous tile
-        //    Res(t,2) | stores(0) | Res(t,3) | stores(1) | ...   with 7 / 14 operations per group (requests for tiles past the end are
-        // issued too, as zero fills, so the counts never change).  The first tile has no stores in front: prologue = Res(0) | T2 | Res(1).
-        tile_rows(first, rv_cur);
-        issue_res(rv_cur, 0);
-        issue_t2(first);
-        issue_res(rv_cur, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();             // biases staged (pairs with the consumers' first barrier)
-        bool first_tile = true;
-        R50_STAMP_DECL
-        for (int tile = first; tile < a.n_tiles; tile += grid) {
-            // T: t2 rows landed.  Younger than T2(t): Res(t,1) [+ stores(7)]
-            if (first_tile) { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
-            __builtin_amdgcn_s_barrier();
-            tile_rows(tile + grid, rv_nxt);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                // R(c): residual(c) landed.  Younger than Res(t,c): see the queue above
-                if (c == 0) {
-                    if (first_tile) { asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); }
-                } else if (c == 1) {
-                    if (first_tile) { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); }
-                } else {
-                    asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
-                }
-                R50_MARK(0)                       // wait: residual landed
-                __builtin_amdgcn_s_barrier();
-                R50_MARK(1)                       // barrier R
-                if (c == NCH - 1) issue_t2(tile + grid);        // every consumer is past A(7): the T2 region is free
-                __builtin_amdgcn_s_barrier();     // O(c): out_c(c) complete, res buffer c & 1 free
-                R50_MARK(2)                       // (t2 issue +) barrier O
-                if (c + 2 < NCH) issue_res(rv_cur, c + 2); else issue_res(rv_nxt, c + 2 - NCH);
-                R50_MARK(3)                       // residual DMA issue
-                copy_out(tile, c);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the copy's LDS reads are complete before this wave arrives at R(c+1))
-                R50_MARK(4)                       // copy-out: LDS reads + store issue
-            }
-            first_tile = false;
-#pragma unroll
-            for (int i = 0; i < 7; ++i) rv_cur[i] = rv_nxt[i];
-        }
-        R50_STAMP_FLUSH(8)
-    } else {
-        // =============================== consumer waves =============================================
-        const int w = wave;
-        const int fr = lane & 15, fq = lane >> 4;
-        const __amdgpu_buffer_rsrc_t rs_y1 = __builtin_amdgcn_make_buffer_rsrc(a.y1n, 0, (unsigned)a.M * (C1N * 2u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wp), 0, 1048576u, 0x00020000);
-        const unsigned wp_voff = (unsigned)(lane * 16 + w * 4096);
-        const int fphys0 = (fq ^ (fr & 7)) << 4;                       // kk = 0; kk = 1 is ^ 64
-        const int x_frag = fr * 128;                                    // + j*2048
-        // the wave's channels 32w .. 32w+31 of a chunk: slot w>>1, 16-B chunk 4(w&1) + fq of a pixel row (residual in, out_c out)
-        const int c_frag = (w >> 1) * SLOT + x_frag + (((4 * (w & 1) + fq) ^ (fr & 7)) << 4);
-        f32x4 accA[2][NR], accB[4][NR];
-        bf16x8 wA[4], wB[4], xq[NR];                 // xq: pixel fragments requested for the coming step (T3_XPRE)
-        // weight fragments of step gs (0..63 of a tile; the stream is the same for every tile), K half kk: wf[kk] (m = 0), wf[2 + kk] (m = 1)
-        auto w_load_half = [&](int gs, bf16x8 (&wf)[4], int kk) {
-            const int sofs = __builtin_amdgcn_readfirstlane((gs & 63) * 16384);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                if constexpr (T3_ABL & 16) wf[2 * m + kk] = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)gs, 1u, 2u, 3u});
-                else wf[2 * m + kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wp, wp_voff + (2 * m + kk) * 1024, sofs, 0));
-            }
-        };
-        auto w_load = [&](int gs, bf16x8 (&wf)[4]) { w_load_half(gs, wf, 0); w_load_half(gs, wf, 1); };
-        // one weight step: acc[m][j] += W[32w + 16m ..][64 K] . X[64 K][16 j ..].  A single set of pixel fragments (the kernel sits at
-        // the 256-register limit): the K = 32..63 fragment of pixel block j replaces the K = 0..31 one as soon as that block's MFMAs
-        // are issued and is consumed 14 MFMAs later; then the fragments of step gs + 2 are requested into the registers this step
-        // has released (order pinned with sched_group_barrier).
-        // T3_XPRE (default 1): the first PD pixel fragments of a step are requested during the LAST slots of the step before it (which
-        // have no reads of their own left) wherever the next step's operand is already complete in LDS -- A0 -> A1 -> A2 -> A3 (t2 is
-        // resident), B0 -> B1 -> B2 -> B3 (out_c is complete behind barrier O) and B3 -> the next chunk's A0 -- so that with ONE consumer wave
-        // per SIMD a step no longer opens with an exposed LDS round trip (stamps: 696 cycles per A step for 448 of MFMA issue).
-        auto w_step = [&](auto pd, auto have_c, auto pdn_c, int gs, bf16x8 (&wf)[4], const char* xb, const char* xnb, f32x4 (&acc0)[NR],
-                          f32x4 (&acc1)[NR], bf16x8 (&xq)[NR]) {
-            // 14 slots t = 7 kk + j, each one pixel fragment and two MFMAs; the fragment of slot t + PD is read when slot t issues.
-            // One wave per SIMD sees ~190 cycles of LDS latency under this load, i.e. 6 slots; the A steps (accA and accB both live)
-            // have registers for PD = 4, the B steps (accA dead) for 7.
-            constexpr int NS = 2 * NR, PD = decltype(pd)::value, PDN = decltype(pdn_c)::value;
-            constexpr bool HAVE = decltype(have_c)::value;
-            static_assert(PDN <= PD, "the next step's first reads ride on this step's read-free slots");
-            bf16x8 x[NS];
-            auto xread = [&](const char* b, int t) { return *reinterpret_cast<const bf16x8*>(b + x_frag + (t % NR) * 2048 + (t >= NR ? (fphys0 ^ 64) : fphys0)); };
-#pragma unroll
-            for (int t = 0; t < PD; ++t) x[t] = HAVE ? xq[t] : xread(xb, t);
-#pragma unroll
-            for (int t = 0; t < NS; ++t) {
-                const int j = t % NR, kk = t / NR;
-                if constexpr (T3_ABL & 4) { asm volatile("" ::"v"(wf[kk]), "v"(wf[2 + kk]), "v"(x[t])); }
-                else {
-                acc0[j] = mfma_e<ET>(wf[kk], x[t], acc0[j]);
-                acc1[j] = mfma_e<ET>(wf[2 + kk], x[t], acc1[j]);
-                }
-                if (t + PD < NS) x[t + PD] = xread(xb, t + PD);
-                else if (t + PD - NS < PDN) xq[t + PD - NS] = xread(xnb, t + PD - NS);
-                // the K half this step has just finished with is requested for step gs + 2 at once (half a step earlier than at the
-                // step's end: the loads come from L2 while every other CU streams too, and one step of cover is not enough)
-                if (t == NR - 1) w_load_half(gs + 2, wf, 0);
-            }
-            w_load_half(gs + 2, wf, 1);
-            if (!HAVE) __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
-#pragma unroll
-            for (int t = 0; t < NS; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                if (t + PD < NS || t + PD - NS < PDN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (t == NR - 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-            // a scheduling region per step: without this fence the scheduler fills a step's "2 MFMAs" groups with MFMAs of LATER steps (same
-            // accumulator chain), which then wait with vmcnt(0) for weight fragments requested a moment ago (seen in the ISA: vmcnt 5, 4, .. 0)
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        w_load(0, wA);
-        w_load(1, wB);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's part of the biases is in LDS ...
-        __builtin_amdgcn_s_barrier();             // ... and after the barrier everybody's
-        R50_STAMP_DECL
-        for (int tile = first; tile < a.n_tiles; tile += grid) {
-            const int p0 = tile * a.bp;
-            const int limit = (a.M - p0 < a.bp) ? a.M - p0 : a.bp;
-            __builtin_amdgcn_s_barrier();         // T: the tile's t2 rows are in LDS
-            R50_MARK(0)                           // barrier T (+ previous tile's y1n stores)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {         // accB[2t + e]: channels 128t + 32w + 8fq + 4e ..
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + B1_OFF + (128 * t + 32 * w + 8 * fq) * 4);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + B1_OFF + (128 * t + 32 * w + 8 * fq + 4) * 4);
-#pragma unroll
-                for (int j = 0; j < NR; ++j) { accB[2 * t][j] = lo; accB[2 * t + 1][j] = hi; }
-            }
-            for (int c = 0; c < NCH; ++c) {
-                {
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + B3_OFF + (c * 128 + 32 * w + 8 * fq) * 4);
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + B3_OFF + (c * 128 + 32 * w + 8 * fq + 4) * 4);
-#pragma unroll
-                    for (int j = 0; j < NR; ++j) { accA[0][j] = lo; accA[1][j] = hi; }
-                }
-                // ---- A: 4 K-slots of W3[c] . t2 (no barriers: weights from this wave's registers, t2 resident)
-                {
-                    using PA = std::integral_constant<int, T3_PDA>;
-                    using NX = std::integral_constant<int, (T3_XPRE & 1) ? T3_PDA : 0>;
-                    using N0 = std::integral_constant<int, 0>;
-                    // (A0's fragments were requested by the previous chunk's B3, except at a tile's first chunk)
-                    if ((T3_XPRE & 4) && c > 0) w_step(PA{}, std::true_type{}, NX{}, c * 8 + 0, wA, smem + T2 + 0 * SLOT, smem + T2 + 1 * SLOT, accA[0], accA[1], xq);
-                    else w_step(PA{}, std::false_type{}, NX{}, c * 8 + 0, wA, smem + T2 + 0 * SLOT, smem + T2 + 1 * SLOT, accA[0], accA[1], xq);
-                    w_step(PA{}, std::integral_constant<bool, (T3_XPRE & 1) != 0>{}, NX{}, c * 8 + 1, wB, smem + T2 + 1 * SLOT, smem + T2 + 2 * SLOT, accA[0], accA[1], xq);
-                    w_step(PA{}, std::integral_constant<bool, (T3_XPRE & 1) != 0>{}, NX{}, c * 8 + 2, wA, smem + T2 + 2 * SLOT, smem + T2 + 3 * SLOT, accA[0], accA[1], xq);
-                    w_step(PA{}, std::integral_constant<bool, (T3_XPRE & 1) != 0>{}, N0{}, c * 8 + 3, wB, smem + T2 + 3 * SLOT, smem + T2, accA[0], accA[1], xq);
-                }
-#if defined(R50_STAMP)
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 0" ::"v"(accA[1][NR - 1]), "v"(accA[0][NR - 1]) : "memory");   // the stamp waits for the last MFMAs
-#endif
-                R50_MARK(1)                       // A: 4 weight steps
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();     // R(c): residual(c) is in LDS; everybody (helpers too) is done with out_c(c-1)
-                R50_MARK(2)                       // barrier R
-                // ---- E: + identity, ReLU, 16-bit -> out_c
-                if (!(T3_ABL & 8)) {
-                    const char* rb = smem + RES + (c & 1) * 2 * SLOT + c_frag;
-                    u32x4 r[NR];
-#pragma unroll
-                    for (int j = 0; j < NR; ++j) r[j] = *reinterpret_cast<const u32x4*>(rb + j * 2048);
-#pragma unroll
-                    for (int j = 0; j < NR; ++j) {
-                        f32x4 lo = accA[0][j], hi = accA[1][j];
-                        lo[0] += unpack_lo_e<ET>(r[j][0]); lo[1] += unpack_hi_e<ET>(r[j][0]);
-                        lo[2] += unpack_lo_e<ET>(r[j][1]); lo[3] += unpack_hi_e<ET>(r[j][1]);
-                        hi[0] += unpack_lo_e<ET>(r[j][2]); hi[1] += unpack_hi_e<ET>(r[j][2]);
-                        hi[2] += unpack_lo_e<ET>(r[j][3]); hi[3] += unpack_hi_e<ET>(r[j][3]);
-                        u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
-                        *reinterpret_cast<u32x4*>(smem + OUTC + c_frag + j * 2048) = o;
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // out_c written before anybody reads it
-                R50_MARK(3)                       // E
-                __builtin_amdgcn_s_barrier();     // O(c)
-                R50_MARK(4)                       // barrier O
-                // ---- B: W1[:, c] . out_c, K-slot kb x cout half h (no barriers)
-                {
-                    using PB = std::integral_constant<int, T3_PDB>;
-                    using NX = std::integral_constant<int, (T3_XPRE & 2) ? T3_PDB : 0>;
-                    using NA = std::integral_constant<int, (T3_XPRE & 4) ? T3_PDA : 0>;
-                    using N0 = std::integral_constant<int, 0>;
-                    using HV = std::integral_constant<bool, (T3_XPRE & 2) != 0>;
-                    w_step(PB{}, std::false_type{}, NX{}, c * 8 + 4, wA, smem + OUTC + 0 * SLOT, smem + OUTC + 0 * SLOT, accB[0], accB[1], xq);
-                    w_step(PB{}, HV{}, NX{}, c * 8 + 5, wB, smem + OUTC + 0 * SLOT, smem + OUTC + 1 * SLOT, accB[2], accB[3], xq);
-                    w_step(PB{}, HV{}, NX{}, c * 8 + 6, wA, smem + OUTC + 1 * SLOT, smem + OUTC + 1 * SLOT, accB[0], accB[1], xq);
-                    // B3 -> the next chunk's A0 (t2 stays resident for the whole tile); nothing after a tile's last chunk
-                    if ((T3_XPRE & 4) && c + 1 < NCH) w_step(PB{}, HV{}, NA{}, c * 8 + 7, wB, smem + OUTC + 1 * SLOT, smem + T2, accB[2], accB[3], xq);
-                    else w_step(PB{}, HV{}, N0{}, c * 8 + 7, wB, smem + OUTC + 1 * SLOT, smem + T2, accB[2], accB[3], xq);
-                }
-#if defined(R50_STAMP)
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 0" ::"v"(accB[3][NR - 1]), "v"(accB[2][NR - 1]), "v"(accB[1][NR - 1]), "v"(accB[0][NR - 1]) : "memory");
-#endif
-                R50_MARK(5)                       // B: 4 weight steps
-            }
-            // ---- next conv1's output: ReLU, 16-bit, 16-B stores (the next tile's first two weight steps are already requested)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    const f32x4 lo = accB[2 * t][j], hi = accB[2 * t + 1][j];
-                    u32x4 o = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
-                    const unsigned voff = (16 * j + fr < limit) ? (unsigned)((p0 + 16 * j + fr) * C1N + 128 * t + 32 * w + 8 * fq) * 2u : kOobOffset;
-                    if (!(T3_ABL & 2) || o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, voff, 0, 0);
-                }
-            R50_MARK(6)                           // y1n epilogue
-        }
-        R50_STAMP_FLUSH(8)
-    }
-#else
-    (void)a;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -5513,155 +4731,6 @@ constexpr int SF_PACK_ROWS = 8;                       // rows per packing thread
 __device__ __forceinline__ unsigned max_bf16x2_nonneg(unsigned a, unsigned b) {   // both operands >= +0: integer order = float order
     typedef __attribute__((ext_vector_type(2))) short s16x2;
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
-}
-
-template <int ET, typename TIN>
-__global__ __launch_bounds__(SF_THREADS) void stem_fused_kernel(const TIN* __restrict__ x, const char* __restrict__ wpk,
-                                                                const float* __restrict__ bias, __bf16* __restrict__ y,
-                                                                int n_tiles, const float* __restrict__ u8_table) {
-    // Persistent: workgroup b handles tiles b, b + grid, ... (tile = image x pooled-row pair).  The fp32 pixels
-    // of tile t+1 are loaded into registers while tile t runs its MFMAs and pooling; the weights are staged once.
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_w = smem;
-    char* s_in = smem + STEM_W_BYTES;
-    char* s_out = smem + STEM_W_BYTES + SF_IN_BYTES;
-    float* s_tab = reinterpret_cast<float*>(smem + STEM_W_BYTES + SF_IN_BYTES + SF_OUT_BYTES);
-    constexpr bool U8 = (sizeof(TIN) == 1);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
-
-    for (int c = tid; c < STEM_W_BYTES / 16; c += SF_THREADS)
-        *reinterpret_cast<u32x4*>(s_w + c * 16) = *reinterpret_cast<const u32x4*>(wpk + c * 16);
-    if constexpr (U8) {                                 // 768 host-computed values ((u8/255) - mean[c]) / std[c]
-        for (int c = tid; c < 3 * 256; c += SF_THREADS) s_tab[c] = u8_table[c];
-    }
-
-    // packing role: one padded column wp (wi = wp - 4) x 8 (or 7) consecutive input rows
-    const int p_half = tid >= STEM_WP ? 1 : 0;
-    const int p_wp = tid - p_half * STEM_WP;
-    const bool p_active = tid < 2 * STEM_WP;
-    const bool p_col_ok = p_active && (unsigned)(p_wp - 4) < 224u;
-    float pc[SF_PACK_ROWS][3];
-    auto load_tile = [&](int tile) {
-        const int n = tile / 28;
-        const int in0 = 4 * ((tile % 28) * 2) - 5 + p_half * SF_PACK_ROWS;    // first input row of this thread
-        const TIN* base = x + (size_t)n * 3 * 224 * 224 + (p_col_ok ? p_wp - 4 : 0);
-#pragma unroll
-        for (int r = 0; r < SF_PACK_ROWS; ++r) {
-            const int hi = in0 + r;
-            const bool ok = p_col_ok && (unsigned)hi < 224u && (p_half * SF_PACK_ROWS + r) < SF_IN_ROWS;
-            const TIN* p = base + (ok ? hi * 224 : 0);
-            if constexpr (U8) {                        // raw bytes now (-1 = outside the image), table look-up at pack time
-                pc[r][0] = ok ? (float)p[0] : -1.f;
-                pc[r][1] = ok ? (float)p[224 * 224] : -1.f;
-                pc[r][2] = ok ? (float)p[2 * 224 * 224] : -1.f;
-            } else {
-                pc[r][0] = ok ? frame_value(p, 0) : 0.f;
-                pc[r][1] = ok ? frame_value(p + 224 * 224, 1) : 0.f;
-                pc[r][2] = ok ? frame_value(p + 2 * 224 * 224, 2) : 0.f;
-            }
-        }
-    };
-    auto sample = [&](float v, int c) -> float {
-        if constexpr (U8) return v < 0.f ? 0.f : s_tab[c * 256 + (int)v];
-        else return v;
-    };
-
-    int tile = blockIdx.x;
-    if (tile < n_tiles) load_tile(tile);
-    for (; tile < n_tiles; tile += gridDim.x) {
-        const int n = tile / 28;
-        const int r0 = (tile % 28) * 2;                // first pooled row
-        // registers -> s_in[row][wp][4] bf16 (zero border / zero rows outside the image)
-        if (p_active) {
-#pragma unroll
-            for (int r = 0; r < SF_PACK_ROWS; ++r) {
-                const int row = p_half * SF_PACK_ROWS + r;
-                if (row < SF_IN_ROWS)
-                    *reinterpret_cast<u32x2*>(s_in + (row * STEM_WP + p_wp) * 8) =
-                        (u32x2){pack2_e<ET>(sample(pc[r][0], 0), sample(pc[r][1], 1)), pack2_e<ET>(sample(pc[r][2], 2), 0.f)};
-            }
-        }
-        __syncthreads();                               // s_in (and, first time, s_w) ready; previous pooling finished
-        if (tile + (int)gridDim.x < n_tiles) load_tile(tile + gridDim.x);
-
-        const int crow = 2 * r0 - 1 + wave;            // conv row of waves 0..4
-        if (wave < SF_CONV_ROWS && crow >= 0 && crow < 112) {
-            f32x4 acc[4][7];
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int j = 0; j < 7; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // conv row c reads input rows 2c-3+kh = (first held row) + 2*wave + kh
-            const int w_frag = fr * 64 + fq * 16;
-            const int x_frag = (2 * wave) * STEM_ROW_BYTES + fr * 16 + fq * 16;
-#pragma unroll
-            for (int kh = 0; kh < 7; ++kh) {
-                bf16x8 wf[4], xf[7];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(s_w + kh * 4096 + m * 1024 + w_frag);
-#pragma unroll
-                for (int j = 0; j < 7; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(s_in + x_frag + kh * STEM_ROW_BYTES + j * 256);
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) acc[m][j] = mfma_e<ET>(wf[m], xf[j], acc[m][j]);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int cout = 32 * t + 8 * fq;
-                const f32x4 b_lo = *reinterpret_cast<const f32x4*>(bias + cout);
-                const f32x4 b_hi = *reinterpret_cast<const f32x4*>(bias + cout + 4);
-#pragma unroll
-                for (int j = 0; j < 7; ++j) {
-                    const int wo = 16 * j + fr;
-                    u32x4 out;
-                    out[0] = relu_bf16x2(pack2_e<ET>(acc[2 * t][j][0] + b_lo[0], acc[2 * t][j][1] + b_lo[1]));
-                    out[1] = relu_bf16x2(pack2_e<ET>(acc[2 * t][j][2] + b_lo[2], acc[2 * t][j][3] + b_lo[3]));
-                    out[2] = relu_bf16x2(pack2_e<ET>(acc[2 * t + 1][j][0] + b_hi[0], acc[2 * t + 1][j][1] + b_hi[1]));
-                    out[3] = relu_bf16x2(pack2_e<ET>(acc[2 * t + 1][j][2] + b_hi[2], acc[2 * t + 1][j][3] + b_hi[3]));
-                    *reinterpret_cast<u32x4*>(s_out + (wave * 112 + wo) * 128 + (((4 * t + fq) ^ (wo & 7)) << 4)) = out;
-                }
-            }
-        }
-        __syncthreads();                               // conv rows complete; s_in free for the next tile
-
-        // pool: thread = (pooled column q, channel group g); horizontal 3-max of each of the 5 conv rows, then the
-        // two vertical 3-maxes (rows 0-2 and 2-4).  All values are post-ReLU (>= +0), so the maximum is taken on the
-        // packed bf16 words with integer max (v_pk_max_i16) and 0 is the identity for the padding taps.
-        if (tid < 56 * 8) {
-            const int g = tid & 7, q = tid >> 3;
-            u32x4 hrow[SF_CONV_ROWS];
-#pragma unroll
-            for (int lrow = 0; lrow < SF_CONV_ROWS; ++lrow) {
-                u32x4 h = (u32x4){0u, 0u, 0u, 0u};
-                const int c = 2 * r0 - 1 + lrow;
-                if (c >= 0 && c < 112) {
-#pragma unroll
-                    for (int dw = 0; dw < 3; ++dw) {
-                        const int wo = 2 * q - 1 + dw;
-                        if (wo >= 0) {                 // wo <= 111 always
-                            const u32x4 v = *reinterpret_cast<const u32x4*>(s_out + (lrow * 112 + wo) * 128 + ((g ^ (wo & 7)) << 4));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) h[e] = max_bf16x2_nonneg(h[e], v[e]);
-                        }
-                    }
-                }
-                hrow[lrow] = h;
-            }
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                u32x4 out;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    out[e] = max_bf16x2_nonneg(max_bf16x2_nonneg(hrow[2 * pr][e], hrow[2 * pr + 1][e]), hrow[2 * pr + 2][e]);
-                *reinterpret_cast<u32x4*>(y + (((size_t)n * 56 + r0 + pr) * 56 + q) * 64 + g * 8) = out;
-            }
-        }
-        // the next iteration's first barrier orders this pooling against the next conv's s_out writes
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -420,13 +420,14 @@ bool is_xres_shape(const ConvArgs& a) {
           a.x_cstride == a.Cin && a.y_cstride == a.Cout && a.Ktot == 9 * a.Cin && a.et != 2)) return false;
     return (a.H == 14 && a.Cin == 256) || (a.H == 7 && a.Cin == 512) || (a.H == 28 && a.Cin == 128);
 }
-template <int ET, int BC, int NI, int TR, int IW, int IH, int TPS, int NST, int SCHED = 0, int RB = 0>
+template <int ET, int NI, int TR, int IW, int IH>
 hipError_t launch_conv3x3_xres_t(ConvArgs a, hipStream_t s) {
-    constexpr int PW = RB ? (IW == 28 ? 32 : 16) : IW + 2;
-    constexpr int PPT = (RB && IW == 7) ? 17 * 16 : NI * (TR + 2) * PW, XBUF = (PPT + 31) / 32 * 32 * 128;
-    constexpr size_t lds = 2 * (size_t)XBUF + NST * (size_t)TPS * BC * 128;
+    constexpr int BC = 128, NST = 3;
+    constexpr int PW = IW == 28 ? 32 : 16;
+    constexpr int PPT = IW == 7 ? 17 * 16 : NI * (TR + 2) * PW, XBUF = (PPT + 31) / 32 * 32 * 128;
+    constexpr size_t lds = 2 * (size_t)XBUF + NST * (size_t)BC * 128;
     static_assert(lds <= 163840, "LDS budget");
-    auto kern = conv3x3_xres_kernel<ET, BC, NI, TR, IW, IH, TPS, NST, SCHED, RB>;
+    auto kern = conv3x3_xres_kernel<ET, NI, TR, IW, IH>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (g_num_cus == 0) {
@@ -438,65 +439,19 @@ hipError_t launch_conv3x3_xres_t(ConvArgs a, hipStream_t s) {
     a.n_ctiles = a.Cout / BC;
     a.n_blocks = ((a.N + NI - 1) / NI) * (IH / TR) * a.n_ctiles;
     const int grid = a.n_blocks < g_num_cus ? a.n_blocks : g_num_cus;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(RB == 3 ? 512 : 768), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, s, a);
     return hipGetLastError();
 }
-int g_xres_variant = [] { const char* v = std::getenv("R50_XRES_VARIANT"); return v ? std::atoi(v) : 0; }();
 template <int ET>
 hipError_t launch_conv3x3_xres(const ConvArgs& a, hipStream_t s) {
     if (!is_xres_shape(a)) return hipErrorInvalidValue;
-    // 14x14: 128 couts x one image x one tap per step (512 tiles = two full rounds at batch 256).  Measured in the network at batch 256
-    // (bench.py, same box, two rounds each): generic tuned tile 82.2-82.5 k frames/s; this 83.1-83.2 k; 256 couts per tile (112
-    // accumulator registers, spills outside the loop) 83.1-83.2 k; a whole kernel row per step (TPS = 3, ring of two 48-KB stages) 82.0 k.
-    // Round 3: the DEFAULT at 14x14 and 28x28 is the row-block form (variant 10: no address arithmetic in the K loop; bit-identical to the
-    // 13-block form, 55.0 -> 51.2 us and 60.6 -> 57.2 us at batch 256, profiles/r03_xres_variants.txt).  Variant 20 = the round-2 default.
-    int var = g_xres_variant;                     // A/B knob (R50_XRES_VARIANT / option "xres_variant")
-    if (var == 0) var = 10;
-    if (var == 20) var = 0;
-    const bool deep = (var == 4);                  // ring of 4 weight stages (3 in flight) instead of 3
-    if (var == 6) {                                // mid-step barrier schedule + deeper weight ring (5 / 4 / 5 stages: 4 / 3 / 4 in flight)
-        if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 5, 1>(a, s);
-        if (a.H == 7) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 4, 1>(a, s);
-        return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 5, 1>(a, s);
-    }
-    if (var == 7) {                                // end-of-step barrier, deeper ring
-        if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 5, 0>(a, s);
-        if (a.H == 7) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 4, 0>(a, s);
-        return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 5, 0>(a, s);
-    }
-    if (var == 10 || var == 11) {                  // row blocks (kernels.h, RB 1): no address arithmetic in the K loop; 11 = 256 couts per tile at 14x14
-        if (a.H == 14) return var == 11 ? launch_conv3x3_xres_t<ET, 256, 1, 14, 14, 14, 1, 3, 0, 1>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 0, 1>(a, s);
-        if (a.H == 28) return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3, 0, 1>(a, s);
-        if (a.H == 7 && var == 10) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 3, 0, 1>(a, s);      // image pairs per row (kernels.h, RB7)
-    }
-    if (var == 14) {                               // row blocks with a deeper weight ring (5 stages, 4 in flight)
-        if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 5, 0, 1>(a, s);
-        if (a.H == 28) return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 5, 0, 1>(a, s);
-        if (a.H == 7) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 5, 0, 1>(a, s);
-    }
-    if (var == 13) {                               // row blocks on the 32x32x16 MFMA, four consumer waves (kernels.h, RB 3)
-        if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 0, 3>(a, s);
-        if (a.H == 28) return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3, 0, 3>(a, s);
-    }
-    if (var == 12) {                               // row blocks + mid-step barrier (kernels.h, RB 2)
-        if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 0, 2>(a, s);
-        if (a.H == 28) return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3, 0, 2>(a, s);
-    }
-    if (var == 8 || var == 9) {                    // staggered SIMD partners (kernels.h, SCHED 2); 9 = with the deeper ring
-        if (a.H == 14) return var == 9 ? launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 5, 2>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 2>(a, s);
-        if (a.H == 7) return var == 9 ? launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 4, 2>(a, s) : launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 3, 2>(a, s);
-        return var == 9 ? launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 5, 2>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3, 2>(a, s);
-    }
-    if (var == 5) {                                // mid-step barrier schedule (kernels.h, SCHED 1)
-        if (a.H == 14) return launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3, 1>(a, s);
-        if (a.H == 7) return launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 3, 1>(a, s);
-        return launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3, 1>(a, s);
-    }
-    if (a.H == 14) return var == 1 ? launch_conv3x3_xres_t<ET, 256, 1, 14, 14, 14, 1, 3>(a, s)
-                        : var == 3 ? launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 3, 2>(a, s)
-                        : deep ? launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 4>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 14, 14, 14, 1, 3>(a, s);
-    if (a.H == 7) return deep ? launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 4>(a, s) : launch_conv3x3_xres_t<ET, 128, 4, 7, 7, 7, 1, 3>(a, s);
-    return deep ? launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 4>(a, s) : launch_conv3x3_xres_t<ET, 128, 1, 7, 28, 28, 1, 3>(a, s);
+    // The row-block form (kernels.h): 128 couts x 196 pixels per tile, one tap per step, ring of three 16-KB weight stages, static loader schedule.
+    // 14x14: one image per tile (512 tiles = two full rounds at batch 256); 28x28: a 7-row band; 7x7: four images (two pairs per 16-position row).
+    // Rounds 2-3 carried eleven more schedules of this kernel (13-block addressing, mid-step barriers, rings of 4-5 stages, staggered SIMD partners,
+    // 256 couts per tile, the 32x32x16 MFMA): all bit-identical, all measured slower or equal (profiles/r03_xres_variants.txt), removed in round 4.
+    if (a.H == 14) return launch_conv3x3_xres_t<ET, 1, 14, 14, 14>(a, s);
+    if (a.H == 28) return launch_conv3x3_xres_t<ET, 1, 7, 28, 28>(a, s);
+    return launch_conv3x3_xres_t<ET, 4, 7, 7, 7>(a, s);
 }
 
 // conv2 of layer2.0 / layer3.0 / layer4.0 (3x3 STRIDE 2 p1, Cin = Cout, 56 -> 28 x 128, 28 -> 14 x 256, 14 -> 7 x 512): input resident by polyphase planes (kernels.h:
@@ -581,7 +536,7 @@ long long tiles_of(const ConvArgs& a, int tile) {
         switch (tile & (kPersistBit - 1)) {
             case 1: case 8: bc = 128; bp = 128; break;  case 2: bc = 64; bp = 128; break;   case 3: bc = 64; bp = 256; break;
             case 5: bc = 128; bp = 64; break;           case 6: bc = 256; bp = 128; break;  case 7: bc = 128; bp = 256; break;
-            case 9: case 10: bc = 256; bp = 256; break; case 11: bc = 256; bp = 208; break; case 12: case 13: bc = 256; bp = 224; break; case 14: bc = 128; bp = 256; break;
+            case 9: case 10: bc = 256; bp = 256; break; case 11: bc = 256; bp = 208; break; case 12: bc = 256; bp = 224; break;
             default: return 0;
         }
     }
@@ -676,9 +631,6 @@ hipError_t launch_igemm_et(const ConvArgs& a, int tile, hipStream_t s, bool spli
         case 10: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<ET, 256, 256, 2, 4, 2>(a, pers, s);
         case 11: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<ET, 256, 208, 8, 1, 2>(a, pers, s);
         case 12: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<ET, 256, 224, 4, 2, 2>(a, pers, s);
-        // 16 waves (4 per SIMD: a register-resident MFMA loop sustains 1.63 / 1.96 / 2.29 PFLOP/s at 1 / 2 / 4 waves per SIMD), wave tile 32c x 112p
-        case 13: if (a.Cout % 256) return hipErrorInvalidValue; return launch_igemm_t<ET, 256, 224, 8, 2, 2>(a, pers, s);
-        case 14: if (a.Cout % 128) return hipErrorInvalidValue; return launch_igemm_t<ET, 128, 256, 4, 4, 3>(a, pers, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -847,15 +799,12 @@ hipError_t pack_tail3_weights(const void* w3, const void* w1, void* wp, hipStrea
     hipLaunchKernelGGL(tail3_pack_kernel, dim3(65536 / 256), dim3(256), 0, s, (const __bf16*)w3, (const __bf16*)w1, (__bf16*)wp);
     return hipGetLastError();
 }
-// variant: 0 = bneck_tail3_kernel (4 consumer + 4 helper waves), 1 = bneck_tail3p_kernel (two-group pipeline, 112 LDS rows per slot),
-// 2 = the same with 98 rows per slot.  Default for the network: g_tail3_variant (env R50_TAIL3_VAR, option "tail3_variant").
-int g_tail3_bp = 0;        // option "tail3_bp": real pixels per tile of the chained layer3 tail (0 = whole rounds of the chip: 98 at batch 256)
-int g_tail3_variant = [] { const char* v = std::getenv("R50_TAIL3_VAR"); return v ? std::atoi(v) : 1; }();
+// bneck_tail3p_kernel (two-group pipeline, 112 LDS rows per slot).  Rounds 2-3 also carried bneck_tail3_kernel (consumer + helper waves) and a 98-row
+// form of the pipeline: both measured slower (profiles/r03_tail3p_variants.txt) and were removed in round 4 (git history has them).
+int g_tail3_bp = 0;        // option "tail3_bp": real pixels per tile of the chained layer3 tail (0 = whole rounds of the chip / full tiles)
 hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const float* b3, const void* res, void* out,
-                              const float* b1, void* y1n, hipStream_t s, int et = 0, int bp_override = 0, int variant = -1, bool no_next = false) {
-    if (no_next) { b1 = b3; y1n = out; }       // conv3 + identity + ReLU only (pipelined kernel, group B copies out): b1 / y1n are not used
-    if (variant < 0) variant = g_tail3_variant;
-    if (no_next) variant = 1;       // conv3 + identity + ReLU only (pipelined kernel, group B copies out): b1 / y1n are not used
+                              const float* b1, void* y1n, hipStream_t s, int et = 0, int bp_override = 0, bool no_next = false) {
+    if (no_next) { b1 = b3; y1n = out; }       // conv3 + identity + ReLU only (group B copies out): b1 / y1n are not used
     if (bp_override == 0) bp_override = g_tail3_bp;
     if (!y2 || !wp || !b3 || !res || !out || !b1 || !y1n || m <= 0 || m * 2048 >= (1ll << 31)) return hipErrorInvalidValue;
     if (g_num_cus == 0) {
@@ -870,35 +819,26 @@ hipError_t launch_bneck_tail3(const void* y2, long long m, const void* wp, const
 #if defined(R50_STAMP)
     a.dbg = g_dbg;
 #endif
-    const int rows = variant == 2 ? 98 : 112;
+    constexpr int rows = 112;
     const long long rounds = ((m + rows - 1) / rows + g_num_cus - 1) / g_num_cus;
     long long bp = (m + rounds * g_num_cus - 1) / (rounds * g_num_cus);
     if (bp < 49) bp = 49;
     if (bp > rows) bp = rows;
-    // the pipelined kernel with more than one round of tiles: FULL tiles (batch 256: 448 tiles of 112 instead of 512 of 98 in 112 rows).  An
-    // eighth of the MFMA columns of a 98-pixel tile multiply padding; the ragged last round that full tiles leave is filled by the other
-    // lane's launches (bench.py --lanes 2: +0.9 % frames/s, two same-box pairs; neutral with one lane)
-    if (variant == 1 && (m + rows - 1) / rows > g_num_cus) bp = rows;
+    // more than one round of tiles: FULL tiles (batch 256: 448 tiles of 112 instead of 512 of 98 in 112 rows).  An eighth of the MFMA columns of a
+    // 98-pixel tile multiply padding; the ragged last round that full tiles leave is filled by the other lane's launches (bench.py --lanes 2:
+    // +0.9 % frames/s, two same-box pairs; neutral with one lane)
+    if ((m + rows - 1) / rows > g_num_cus) bp = rows;
     if (bp_override >= 1 && bp_override <= rows) bp = bp_override;
     a.bp = (int)bp;
     a.n_tiles = (int)((m + bp - 1) / bp);
     const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
-    if (variant == 1 || variant == 2) {
-        const size_t ldsp = 8 * (size_t)rows * 128 + 256 * 4 + 1024 * 4;      // t2 (4 slots) + out_c (2 x 2) + b1 + b3
-        void (*kp)(const Tail3Args);
-        if (no_next) kp = et == 1 ? bneck_tail3p_kernel<1, 112, true> : bneck_tail3p_kernel<0, 112, true>;
-        else if (variant == 1) kp = et == 1 ? bneck_tail3p_kernel<1, 112> : bneck_tail3p_kernel<0, 112>;
-        else kp = et == 1 ? bneck_tail3p_kernel<1, 98> : bneck_tail3p_kernel<0, 98>;
-        hipError_t ep = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
-        if (ep != hipSuccess) return ep;
-        hipLaunchKernelGGL(kp, dim3(grid), dim3(512), ldsp, s, a);
-        return hipGetLastError();
-    }
-    const size_t lds = 10 * 112 * 128 + 256 * 4 + 1024 * 4;      // t2 (4 slots) + residual (2 x 2) + out_c (2) + b1 + b3
-    auto kern = et == 1 ? bneck_tail3_kernel<1> : bneck_tail3_kernel<0>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
+    const size_t ldsp = 8 * (size_t)rows * 128 + 256 * 4 + 1024 * 4;      // t2 (4 slots) + out_c (2 x 2) + b1 + b3
+    void (*kp)(const Tail3Args);
+    if (no_next) kp = et == 1 ? bneck_tail3p_kernel<1, 112, true> : bneck_tail3p_kernel<0, 112, true>;
+    else kp = et == 1 ? bneck_tail3p_kernel<1, 112> : bneck_tail3p_kernel<0, 112>;
+    hipError_t ep = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+    if (ep != hipSuccess) return ep;
+    hipLaunchKernelGGL(kp, dim3(grid), dim3(512), ldsp, s, a);
     return hipGetLastError();
 }
 
@@ -1085,49 +1025,37 @@ hipError_t launch_stem_conv(const void* xp, const void* wpk, const float* bias, 
                        (const char*)xp, (const char*)wpk, bias, (__bf16*)y);
     return hipGetLastError();
 }
-// fused stem variant: 0 = strip version (stem_fused2_kernel) with the strip length chosen from the batch, 1/2/4/7/14/28 = that strip
-// length, -1 = the per-pair version (stem_fused_kernel).  r50_set_option("stem_strip") or R50_STEM_STRIP in the environment (A/B).
-static int g_stem_strip = [] { const char* v = std::getenv("R50_STEM_STRIP"); return v ? std::atoi(v) : 0; }();
-bool stem_strip_enabled() { return g_stem_strip >= 0; }
-// c1_w / c1_bias / y1 non-null (strip version only): layer1.0.conv1 (+ bias + ReLU) of the pooled output into y1 in the same launch
+// fused stem (stem_fused2_kernel, strip version): strip length 0 = chosen from the batch, 1/2/4/7/14/28 = that many pooled-row pairs per strip.
+// r50_set_option("stem_strip") or R50_STEM_STRIP in the environment (A/B).  (The per-pair kernel of round 1, stem_fused_kernel, was removed in round 4.)
+static int g_stem_strip = [] { const char* v = std::getenv("R50_STEM_STRIP"); const int g = v ? std::atoi(v) : 0; return g > 0 && 28 % g == 0 ? g : 0; }();
+bool stem_strip_enabled() { return true; }
+// c1_w / c1_bias / y1 non-null: layer1.0.conv1 (+ bias + ReLU) of the pooled output into y1 in the same launch
 template <typename TIN>
 hipError_t launch_stem_fused(const TIN* x, const void* wpk, const float* bias, void* y, int n, hipStream_t s,
                              const float* u8_table, int et = 0, const void* c1_w = nullptr, const float* c1_bias = nullptr,
                              void* y1 = nullptr) {
-    auto kern = et == 1 ? stem_fused_kernel<1, TIN> : stem_fused_kernel<0, TIN>;
-    {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
-        if (e != hipSuccess) return e;
-    }
     if (g_num_cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
         g_num_cus = cu_budget(prop.multiProcessorCount);
     }
-    if (g_stem_strip >= 0) {
-        // strip version: a workgroup walks G consecutive pooled-row pairs of one image; G = the longest strip that still gives
-        // the chip ~200 workgroups (28 = the whole image from batch 200 up)
-        int G = 1;
-        if (g_stem_strip > 0) G = g_stem_strip;
-        else
-            for (int cand : {28, 14, 7, 4, 2})
-                if (n * (28 / cand) >= 200) { G = cand; break; }
-        const bool c1 = c1_w && c1_bias && y1;
-        auto kern2 = c1 ? (et == 1 ? stem_fused2_kernel<1, TIN, true> : stem_fused2_kernel<0, TIN, true>)
-                        : (et == 1 ? stem_fused2_kernel<1, TIN, false> : stem_fused2_kernel<0, TIN, false>);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, SF2_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        const int strips = n * (28 / G);
-        const int grid2 = strips < g_num_cus ? strips : g_num_cus;
-        hipLaunchKernelGGL(kern2, dim3(grid2), dim3(SF_THREADS), SF2_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, strips, G, u8_table,
-                           (const __bf16*)c1_w, c1_bias, (__bf16*)y1);
-        return hipGetLastError();
-    }
-    if (c1_w) return hipErrorInvalidValue;            // the per-pair version has no conv1 stage
-    const int tiles = n * 28;
-    const int grid = tiles < g_num_cus ? tiles : g_num_cus;       // 128 KB of LDS: one workgroup per CU
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, tiles, u8_table);
+    // a workgroup walks G consecutive pooled-row pairs of one image; G = the longest strip that still gives the chip ~200 workgroups
+    // (28 = the whole image from batch 200 up)
+    int G = 1;
+    if (g_stem_strip > 0) G = g_stem_strip;
+    else
+        for (int cand : {28, 14, 7, 4, 2})
+            if (n * (28 / cand) >= 200) { G = cand; break; }
+    const bool c1 = c1_w && c1_bias && y1;
+    auto kern2 = c1 ? (et == 1 ? stem_fused2_kernel<1, TIN, true> : stem_fused2_kernel<0, TIN, true>)
+                    : (et == 1 ? stem_fused2_kernel<1, TIN, false> : stem_fused2_kernel<0, TIN, false>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, SF2_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int strips = n * (28 / G);
+    const int grid2 = strips < g_num_cus ? strips : g_num_cus;
+    hipLaunchKernelGGL(kern2, dim3(grid2), dim3(SF_THREADS), SF2_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, strips, G, u8_table,
+                       (const __bf16*)c1_w, c1_bias, (__bf16*)y1);
     return hipGetLastError();
 }
 template <typename TIN>
@@ -1530,15 +1458,14 @@ after_pool:
                 if (rc) return rc;
                 h3 = h2; w3 = w2;
             } else if (si == 2 && b == blocks - 1 && b < 8 && h->tail3_wp[b] && h->fuse_tail3 && h->fuse_tail3_last && h->fuse_tail && !split && !tap && h->tile_override == 0 &&
-                       (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16) && c3.ks == 1 && c3.cin == 256 && c3.cout == 1024 && idn == buf[cur] &&
-                       g_tail3_variant >= 1) {
+                       (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16) && c3.ks == 1 && c3.cin == 256 && c3.cout == 1024 && idn == buf[cur]) {
                 // layer3.5: conv3 + identity + ReLU through the pipelined tail kernel without a second GEMM (its next conv1, layer4.0's 1024 -> 512, does
                 // not fit the chain): same bits as the igemm launch, whose K = 256 tiles alternate between an MFMA phase and an epilogue phase
                 const long long m = (long long)n * h2 * w2;
                 EvRec rt{};
                 prof_begin(h, s, rt, PC_TAIL3, 2.0 * m * (double)c3.cout * c3.cin, 2.0 * (m * ((double)c3.cin + 2.0 * c3.cout) + (double)c3.cout * c3.cin),
                            (int)(&c3 - &h->convs[0]));
-                e = launch_bneck_tail3(buf[fr[1]], m, h->tail3_wp[b], c3.bias, idn, outb, nullptr, nullptr, s, et, 0, -1, /*no_next=*/true);
+                e = launch_bneck_tail3(buf[fr[1]], m, h->tail3_wp[b], c3.bias, idn, outb, nullptr, nullptr, s, et, 0, /*no_next=*/true);
                 prof_end(h, s, rt);
                 if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_tail3 (no next conv1) launch (" + c3.conv_key + "): " + hipGetErrorString(e));
                 h3 = h2; w3 = w2;
@@ -1974,12 +1901,11 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "fuse_cat_chain") h->fuse_cat_chain = value ? 1 : 0;
     else if (k == "fuse_tail3_last") h->fuse_tail3_last = value ? 1 : 0;
     else if (k == "tail3_bp") { if (value < 0 || value > 112) return fail(h, R50_ERR_INVALID, "tail3_bp must be 0 .. 112"); g_tail3_bp = (int)value; }
-    else if (k == "tail3_variant") { if (value < 0 || value > 2) return fail(h, R50_ERR_INVALID, "tail3_variant must be 0, 1 or 2"); g_tail3_variant = (int)value; }
     else if (k == "fuse_fp8_handover") h->fuse_fp8_handover = value ? 1 : 0;
     else if (k == "fuse_stem_c1") h->fuse_stem_c1 = value ? 1 : 0;
     else if (k == "fuse_ds_cat") h->fuse_ds_cat = value ? 1 : 0;
     else if (k == "stem_strip") {          // process-wide (the launcher is shared by the handle and the r50_op_* hooks)
-        if (!(value == -1 || value == 0 || (value > 0 && 28 % value == 0))) return fail(h, R50_ERR_INVALID, "stem_strip must be -1, 0 or a divisor of 28");
+        if (!(value == 0 || (value > 0 && 28 % value == 0))) return fail(h, R50_ERR_INVALID, "stem_strip must be 0 or a divisor of 28");
         g_stem_strip = (int)value;
     }
     else if (k == "overlap_ds") h->overlap_ds = value ? 1 : 0;
@@ -1987,7 +1913,6 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "inplace_out") h->inplace_out = value ? 1 : 0;
     else if (k == "fuse_block2") h->fuse_block2 = value ? 1 : 0;
     else if (k == "fuse_block1") { if (value < 0 || value > 3) return fail(h, R50_ERR_INVALID, "fuse_block1 must be 0 .. 3"); h->fuse_block1 = (int)value; }
-    else if (k == "xres_variant") g_xres_variant = (int)value;        // process-wide A/B knob
     else if (k == "use_g8") { if (value < 0 || value > 3) return fail(h, R50_ERR_INVALID, "use_g8 must be 0 .. 3"); g_use_g8 = (int)value; }   // process-wide A/B knob
     else if (k == "use_s2") g_use_s2 = (int)value;                     // process-wide A/B knob: 0 = generic tiles for the stride-2 3x3 shapes
     else if (k == "cu_cap") { if (value < 0 || value > 4096) return fail(h, R50_ERR_INVALID, "cu_cap must be in [0,4096]"); g_cu_cap = (int)value; g_num_cus = 0; }
@@ -2009,7 +1934,6 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "fused_stem") *value = h->fused_stem;
     else if (k == "fuse_tail") *value = h->fuse_tail;
     else if (k == "fuse_tail3") *value = h->fuse_tail3;
-    else if (k == "tail3_variant") *value = g_tail3_variant;
     else if (k == "tail3_bp") *value = g_tail3_bp;
     else if (k == "use_g8") *value = g_use_g8;
     else if (k == "fuse_cat_chain") *value = h->fuse_cat_chain;
@@ -2158,20 +2082,19 @@ int r50_op_bneck_tail(const void* y2, int64_t m, int cmid, const void* w3, const
         if (hipMallocAsync(&wp_scratch, kTail3PackedBytes, (hipStream_t)stream) != hipSuccess || !wp_scratch)
             return fail(nullptr, R50_ERR_HIP, "r50_op_bneck_tail: hipMallocAsync");
         e = pack_tail3_weights(w3, w3, wp_scratch, (hipStream_t)stream);
-        if (e == hipSuccess) e = launch_bneck_tail3(y2, m, wp_scratch, b3, res, out, nullptr, nullptr, (hipStream_t)stream, 0, 0, -1, /*no_next=*/true);
+        if (e == hipSuccess) e = launch_bneck_tail3(y2, m, wp_scratch, b3, res, out, nullptr, nullptr, (hipStream_t)stream, 0, 0, /*no_next=*/true);
         const hipError_t ef = hipFreeAsync(wp_scratch, (hipStream_t)stream);
         if (e == hipSuccess) e = ef;
     }
     else if (cmid == 256 && c1 == 256 && !wd && !bd) {
         const char* v = std::getenv("R50_TAIL3_BP");          // test / A-B knob of this debug hook: real pixels per tile (1..112); unset = automatic
-        const char* vv = std::getenv("R50_TAIL3_VAR");        // kernel variant (launch_bneck_tail3), read per call so that one process can A/B
         // the hook takes plain weight matrices: packed here, per call, into a buffer allocated AND freed in the caller's stream order on the
         // caller's current device (a process-wide scratch buffer would be shared by callers on other streams / devices: round-2 ADVICE)
         void* wp_scratch = nullptr;
         if (hipMallocAsync(&wp_scratch, kTail3PackedBytes, (hipStream_t)stream) != hipSuccess || !wp_scratch)
             return fail(nullptr, R50_ERR_HIP, "r50_op_bneck_tail: hipMallocAsync");
         e = pack_tail3_weights(w3, w1, wp_scratch, (hipStream_t)stream);
-        if (e == hipSuccess) e = launch_bneck_tail3(y2, m, wp_scratch, b3, res, out, b1, y1n, (hipStream_t)stream, 0, v ? std::atoi(v) : 0, vv ? std::atoi(vv) : -1);
+        if (e == hipSuccess) e = launch_bneck_tail3(y2, m, wp_scratch, b3, res, out, b1, y1n, (hipStream_t)stream, 0, v ? std::atoi(v) : 0);
         const hipError_t ef = hipFreeAsync(wp_scratch, (hipStream_t)stream);
         if (e == hipSuccess) e = ef;
     }

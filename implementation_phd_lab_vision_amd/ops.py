@@ -25,8 +25,6 @@ TILE_256x256 = 9         # 8 waves, 2 LDS stages, wave tile 64c x 128p
 TILE_256x256_B = 10      # 8 waves, 2 LDS stages, wave tile 128c x 64p
 TILE_256x208 = 11        # 8 waves, 2 LDS stages, wave tile 32c x 208p (208 = 13 x 16 fits M = 2^10 * 49)
 TILE_256x224 = 12        # 8 waves, 2 LDS stages, wave tile 64c x 112p
-TILE_256x224_W16 = 13    # 16 waves (4 per SIMD), 2 LDS stages, wave tile 32c x 112p: measured no faster than the 8-wave tiles
-TILE_128x256_W16 = 14    # 16 waves, 3 LDS stages, wave tile 32c x 64p
 WS = 64                  # role-specialised kernel (4 loader waves + 4 or 8 consumer waves, one workgroup per CU):
                          # WS|1 = 128x128 (4), WS|3 = 256x128 (8), WS|4 = 128x224 (4), WS|8 = 128x224 (8), WS|9 = 64x224 (4), WS|10 = 128x208 (4)
 TILE_XRES = 81           # 3x3 s1 p1 with Cin = Cout on 28x28 (128), 14x14 (256), 7x7 (512): input resident in LDS, only the weights stream (the automatic choice for these shapes)

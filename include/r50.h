@@ -119,9 +119,10 @@ int r50_forward_layer(r50_handle* h, const float* x_nchw_f32_dev, int n, const c
  * "tile" (force an igemm tile id for every conv, 0 = tuned table; also turns "fuse_tail" off),
  * measurement knobs, all results bit-identical: "inplace_out" (1 = plain-identity blocks write their output over their input;
  * default 0), and PROCESS-WIDE ones (they apply to every handle of the process): "cu_cap" (workgroups a persistent launch may use,
- * 0 = every CU; for pipelines that share the chip), "xres_variant" (schedule of the input-resident 3x3 kernel: 0 = default, 5 = mid-step
- * barrier, 6 = + deeper weight ring, 7 = deeper ring only), "tail3_variant" (kernel of the chained layer3 tail: 0 = bneck_tail3_kernel,
- * 1 = bneck_tail3p_kernel, the default, 2 = the same with 98-row LDS slots) and "tail3_bp" (its real pixels per tile, 0 = automatic). */
+ * 0 = every CU; for pipelines that share the chip), "tail3_bp" (real pixels per tile of the chained layer3 tail, 0 = automatic), "use_g8" (the
+ * eight-phase GEMM tiles of gemm8p_kernel for the streaming 1x1 convs: 0 = never, 1 = on the shapes where they measured faster, the default,
+ * 2 / 3 = wherever the shape fits, 256 / 224 pixels per tile), "use_s2" (0 = generic tiles for the stride-2 3x3 shapes) and "stem_strip"
+ * (pooled-row pairs per strip of the fused stem kernel, 0 = chosen from the batch). */
 int r50_set_option(r50_handle* h, const char* key, int64_t value);
 int r50_get_option(r50_handle* h, const char* key, int64_t* value);
 
@@ -207,7 +208,7 @@ int r50_op_maxpool(const void* x_nhwc_bf16, int n, int h, int w, int c, void* y_
  * (c1 = 256, layer3: the chained kernel, weights packed into fragment order per call by this hook) is bit for
  * bit again.  cmid = 256 with c1 = 0 and w1 = b1 = y1n = NULL: conv3 + identity + ReLU ALONE through the same pipelined kernel (the form the
  * stage's last block, layer3.5, runs in; bit for bit a 1x1 r50_op_conv2d with a residual).  (Environment R50_TAIL3_BP = 1..112: pixels per tile
- * of the cmid = 256 kernel, R50_TAIL3_VAR = 0..2: its variant; test knobs.) */
+ * of the cmid = 256 kernel; a test knob.) */
 int r50_op_bneck_tail(const void* y2_bf16, int64_t m, int cmid, const void* w3_bf16, const float* b3,
                       const void* identity_bf16, const void* wd_bf16, const float* bd, void* out_bf16, const void* w1_bf16,
                       int c1, const float* b1, void* y1n_bf16, void* stream);

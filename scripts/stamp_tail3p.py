@@ -1,9 +1,8 @@
 """In-kernel cycle stamps of the pipelined layer3 tail (bneck_tail3p_kernel): where a group-A / group-B wave's time goes.
 Needs the diagnostic build:  scripts/build_variant.sh _stamp -DR50_STAMP=1
-usage: R50_TAIL3_VAR=1 R50_LIB=$PWD/implementation_phd_lab_vision_amd/libr50hip_stamp.so python scripts/stamp_tail3p.py [batch]"""
+usage: R50_LIB=$PWD/implementation_phd_lab_vision_amd/libr50hip_stamp.so python scripts/stamp_tail3p.py [batch]"""
 import ctypes, os, sys, torch
 sys.path.insert(0, '.')
-os.environ.setdefault("R50_TAIL3_VAR", "1")
 from implementation_phd_lab_vision_amd import ops, _lib
 lib = _lib.load_library()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256

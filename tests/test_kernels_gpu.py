@@ -78,9 +78,9 @@ def _tiles_for(cout, k=3, pad=1):
     from implementation_phd_lab_vision_amd import ops
     t = [ops.TILE_AUTO, ops.TILE_64x128, ops.TILE_64x256]
     if cout % 128 == 0:
-        t += [ops.TILE_128x128, ops.TILE_128x64, ops.TILE_128x256_P3, ops.TILE_128x128_P3, ops.TILE_128x256_W16]
+        t += [ops.TILE_128x128, ops.TILE_128x64, ops.TILE_128x256_P3, ops.TILE_128x128_P3]
     if cout % 256 == 0:
-        t += [ops.TILE_256x128_P3, ops.TILE_256x256, ops.TILE_256x256_B, ops.TILE_256x208, ops.TILE_256x224, ops.TILE_256x224_W16]
+        t += [ops.TILE_256x128_P3, ops.TILE_256x256, ops.TILE_256x256_B, ops.TILE_256x208, ops.TILE_256x224]
     ws = [ops.WS | 9]
     if cout % 128 == 0:
         ws += [ops.WS | 1, ops.WS | 4, ops.WS | 8]
@@ -163,37 +163,29 @@ def test_gemm8p_tiles_give_the_bits_of_the_generic_tiles(lib_built, shape, et):
 
 @pytest.mark.parametrize("shape", [(5, 7, 512), (3, 28, 128), (3, 14, 256), (70, 14, 256), (300, 14, 256), (260, 7, 512)],
                          ids=lambda v: "n%d_%dx%d_c%d" % (v[0], v[1], v[1], v[2]))
-def test_xres_schedule_variants_bit_identical(lib_built, shape):
-    """conv3x3_xres_kernel: the row-block form (round 3 default at 14x14 / 28x28), the mid-step-barrier schedule, the deeper weight
-    rings, the staggered schedule and the 32x32x16 form are re-schedulings of the same K order per accumulator -- the same bits as the
-    13-block schedule, also with several tiles per workgroup (n = 300 at 14x14: 600 tiles on 256 CUs) and with panels / cout tiles left ragged."""
+def test_xres_kernel_is_batch_invariant_and_stays_inside_its_output(lib_built, shape):
+    """conv3x3_xres_kernel (row blocks) with several tiles per workgroup (n = 300 at 14x14: 600 tiles on 256 CUs: the stream of weight stages and
+    input chunks crosses tile borders) and with panels / cout tiles left ragged: every image's result is the same bits as when the image is run
+    alone, the generic kernel agrees to the bf16 tolerance (its K order differs), and nothing is stored past the output (poisoned guard band).
+    (Rounds 2-3 compared eleven schedule variants of this kernel bit for bit here; they were removed in round 4.)"""
     from implementation_phd_lab_vision_amd import ops
-    from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
     n, hw, c = shape
     g = torch.Generator().manual_seed(n * 1000 + hw)
     d = _dev()
     x = _rand_bf16((n, hw, hw, c), g).to(d)
     wt = _rand_bf16((c, 3, 3, c), g, scale=(2.0 / (9 * c)) ** 0.5).to(d)
     bias = (torch.randn(c, generator=g) * 0.1).to(d)
-    bb = ResNet50Backbone(seed=0, max_batch=2).to(d)       # only to reach the process-wide option
-    try:
-        ref = None
-        # 0 = default (row blocks at 14x14 / 28x28), 20 = the 13-block form, 5-7 mid-step barrier / deeper rings, 8 staggered SIMD partners,
-        # 12 row blocks + mid-step barrier, 13 row blocks on the 32x32x16 MFMA with four consumer waves, 14 row blocks with a ring of 5 weight stages
-        for var in (20, 0, 5, 6, 7, 8, 10, 12, 13, 14, 0):
-            bb.set_option("xres_variant", var)
-            numel = n * hw * hw * c
-            buf = torch.full((numel + 512 * c,), -7.0, dtype=torch.bfloat16, device=d)
-            y = ops.conv2d_bf16(x, wt, bias, stride=1, pad=1, relu=True, tile=ops.TILE_XRES, out=buf)
-            torch.cuda.synchronize()
-            assert bool((buf[numel:] == -7.0).all()), f"variant {var}: wrote past the end of the output"
-            if ref is None:
-                ref = y.clone()
-            else:
-                assert torch.equal(y, ref), f"xres variant {var} differs from the default schedule"
-    finally:
-        bb.set_option("xres_variant", 0)
-        bb.close()
+    numel = n * hw * hw * c
+    buf = torch.full((numel + 512 * c,), -7.0, dtype=torch.bfloat16, device=d)
+    y = ops.conv2d_bf16(x, wt, bias, stride=1, pad=1, relu=True, tile=ops.TILE_XRES, out=buf)
+    torch.cuda.synchronize()
+    assert bool((buf[numel:] == -7.0).all()), "wrote past the end of the output"
+    for i in sorted({0, n // 2, n - 1}):
+        alone = ops.conv2d_bf16(x[i:i + 1].contiguous(), wt, bias, stride=1, pad=1, relu=True, tile=ops.TILE_XRES)
+        assert torch.equal(alone[0], y[i]), f"image {i} of {n} differs from the same image run alone"
+    gen = ops.conv2d_bf16(x[:2].contiguous(), wt, bias, stride=1, pad=1, relu=True, tile=ops.WS | 8)
+    d2 = (gen.float() - y[:2].float()).abs()
+    assert float(d2.max()) <= 2.0 ** -6 * max(1.0, float(y[:2].float().abs().max())), float(d2.max())
 
 
 @pytest.mark.parametrize("shape", [(1, 56, 128), (70, 56, 128), (300, 56, 128), (5, 28, 256), (300, 28, 256), (3, 14, 512), (300, 14, 512)],
@@ -390,18 +382,16 @@ def _tail3_inputs(n, h, w, seed):
     return y2, w3, b3, idn, w1, b1
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2], ids=lambda v: "var%d" % v)
 @pytest.mark.parametrize("shape,bp", [((2, 7, 9), 0), ((1, 14, 14), 0), ((3, 14, 14), 112), ((3, 14, 14), 98), ((20, 14, 14), 7), ((5, 14, 14), 33)],
                          ids=lambda v: str(v).replace(" ", ""))
-def test_bneck_tail_layer3_shapes(lib_built, shape, bp, variant, monkeypatch):
+def test_bneck_tail_layer3_shapes(lib_built, shape, bp, monkeypatch):
     """Chained layer3 tail (conv3 256->1024 + identity + ReLU, next conv1 1024->256 + ReLU; weights streamed through the LDS ring,
     the residual as one more K-step against an identity operand, the block output handed to the second GEMM through LDS).
     Against the oracle's two fused-op emulations, and BIT FOR BIT against the two igemm launches it replaces (same summation
-    orders).  bp = real pixels per tile: ragged tiles, several tiles per workgroup (bp 7: 560 tiles) and the batch-256 value (98).
-    variant: 0 = bneck_tail3_kernel, 1 / 2 = bneck_tail3p_kernel (two-group pipeline; 112 / 98 LDS rows per slot: bp 112 is capped at 98 there)."""
+    orders).  bp = real pixels per tile: ragged tiles, several tiles per workgroup (bp 7: 560 tiles), full 112-pixel tiles and 98.
+    The kernel is bneck_tail3p_kernel (two-group pipeline); rounds 2-3's bneck_tail3_kernel and the 98-row form were removed in round 4."""
     from implementation_phd_lab_vision_amd import ops
     from oracle.resnet50_oracle import conv_bias_act_emulated
-    monkeypatch.setenv("R50_TAIL3_VAR", str(variant))
     n, h, w = shape
     y2, w3, b3, idn, w1, b1 = _tail3_inputs(n, h, w, 3000 + n * h * w + bp)
     d = _dev()
@@ -431,12 +421,10 @@ def test_bneck_tail_layer3_shapes(lib_built, shape, bp, variant, monkeypatch):
         _check_bf16(y1n, y1_ref, "bneck_tail3 y1n")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2], ids=lambda v: "var%d" % v)
-def test_bneck_tail_layer3_batch256_equals_unfused(lib_built, variant, monkeypatch):
-    """The benchmarked size (256 x 14 x 14 = 50,176 pixels -> 512 tiles of 98, two per workgroup): bit-identical to the launches it replaces."""
+def test_bneck_tail_layer3_batch256_equals_unfused(lib_built, monkeypatch):
+    """The benchmarked size (256 x 14 x 14 = 50,176 pixels -> 448 full tiles of 112, up to two per workgroup): bit-identical to the launches it replaces."""
     from implementation_phd_lab_vision_amd import ops
     monkeypatch.delenv("R50_TAIL3_BP", raising=False)
-    monkeypatch.setenv("R50_TAIL3_VAR", str(variant))
     y2, w3, b3, idn, w1, b1 = _tail3_inputs(256, 14, 14, 3999)
     d = _dev()
     y2d = y2.permute(0, 2, 3, 1).contiguous().to(d)

@@ -190,10 +190,9 @@ def test_fused_stem_equals_unfused(setup):
     fused = bb.layer(xd, "pool")                       # fused kernel (the 'stem' tap alone forces the unfused path)
     unfused = ops.maxpool_bf16(bb.layer(xd, "stem").contiguous())
     assert torch.equal(fused, unfused)
-    # every strip length of the strip kernel (workgroup = G consecutive pooled-row pairs of an image, shared rows kept in LDS
-    # rings) and the per-pair kernel (-1): all the same bits
+    # every strip length of the strip kernel (workgroup = G consecutive pooled-row pairs of an image, shared rows kept in LDS rings): the same bits
     try:
-        for g in (1, 2, 4, 7, 14, 28, -1):
+        for g in (1, 2, 4, 7, 14, 28):
             bb.set_option("stem_strip", g)
             assert torch.equal(bb.layer(xd, "pool"), unfused), g
     finally:
@@ -457,21 +456,6 @@ def test_layer3_chained_tail_is_bit_identical_to_separate_launches(setup):
     assert torch.equal(fused, plain)
 
 
-def test_layer3_tail_kernel_variants_give_the_same_features(setup):
-    """option tail3_variant: 0 = bneck_tail3_kernel (consumer + helper waves), 1 (default) = bneck_tail3p_kernel (two-group pipeline),
-    2 = the same with 98-row LDS slots -- same features bit for bit."""
-    bb, x, *_ = setup
-    xd = x.to("cuda:0")
-    assert bb.get_option("tail3_variant") == 1
-    ref = bb.features(xd).clone()
-    try:
-        for v in (0, 2):
-            bb.set_option("tail3_variant", v)
-            assert torch.equal(bb.features(xd), ref), v
-    finally:
-        bb.set_option("tail3_variant", 1)
-
-
 def test_fp8_handover_in_the_conv_epilogue_is_bit_identical(setup_fp8):
     """fp8 mode: layer1's 16-bit output is quantised to e4m3 inside layer1.2.conv3's epilogue (same rounding sequence: 16-bit result,
     then x 1/scale, then e4m3) -- same features as with the separate quantisation pass, at batch sizes on both sides of the tile rule."""
@@ -532,9 +516,9 @@ def test_backbone_lanes_give_the_bits_of_one_backbone():
         y = two.features(x)
         assert torch.equal(y, refs[2])
         assert two(xs[1]).shape == (5, 2048, 1, 1)
-        two.set_option("tail3_variant", 0)
-        assert two.lane0.get_option("tail3_variant") == 0
-        two.set_option("tail3_variant", 1)
+        two.set_option("tail3_bp", 98)                     # options go to every lane
+        assert two.lane0.get_option("tail3_bp") == 98
+        two.set_option("tail3_bp", 0)
         # the lanes read ONE copy of the weights (r50_share_weights): lane 1 survives lane 0's handle, and a third backbone can join
         # neither the owner (it has a sharer) nor the sharer may take new weights: their buffers are read by the other lane's launches
         for bb in two._bbs:
