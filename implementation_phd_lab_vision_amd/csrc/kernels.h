@@ -4955,6 +4955,370 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused2_kernel(const TIN* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused stem, role-split version (round 4): the arithmetic and the output bits of stem_fused2_kernel, but conv and everything else
+// run side by side instead of in turn.  12 waves: waves 0-7 are the conv waves (conv row rr = wave >> 1 of the pair, channel half
+// ch = wave & 1; two per SIMD), waves 8-11 the service waves (one per SIMD): they pack the NEXT pair's 8 input rows into the ring
+// (fp32 frames with 16-B loads, one thread = 4 pixels x 3 channels), pool the PREVIOUS pair's conv rows, store the pooled rows and
+// run layer1.0.conv1 on the pair before that.  One barrier per pair (stem_fused2: two, with the MFMA pipe idle during pack and pool).
+//   * conv1's weights live in registers (7 kernel rows x 2 fragment blocks x 4 registers per conv wave): the K loop reads only the
+//     7 image fragments per kernel row from LDS, for 14 MFMAs;
+//   * the horizontal half of MaxPool2d(3,2,1) happens in the conv epilogue, in registers: a lane holds pixel wo = 16 j + fr of its
+//     8 channels, its neighbours wo -/+ 1 are the lanes fr -/+ 1 of the same 16-lane row (DPP row_shr / row_shl; pixel 16 j - 1 is
+//     lane 15 of block j - 1, row_ror), and only the even lanes (the window centres wo = 2 q) write: a conv row costs 56 x 128 B of
+//     LDS instead of 112 x 128 B, and the vertical half reads 3 values per output instead of 9;
+//   * rings: 24 input-row slots (the pair being read spans 15 rows, the 8 rows being written follow it), 10 h-pooled conv rows
+//     (5 being pooled + 4 being written), two pooled-pair buffers for C1.
+// LDS: input ring 24 x 1,856 B | h-pooled conv ring 10 x 56 x 128 B | pooled pairs 2 x 14,336 B | u8 table 3,072 B = 147,968 B.
+// ------------------------------------------------------------------------------------------------
+constexpr int SF3_THREADS = 768;
+constexpr int SF3_SVC = 256;                           // service threads
+constexpr int SF3_IN_SLOTS = 24;
+constexpr int SF3_H_SLOTS = 10;
+constexpr int SF3_H_ROW_BYTES = 56 * 128;
+constexpr int SF3_IN_BYTES = SF3_IN_SLOTS * STEM_ROW_BYTES;
+constexpr int SF3_H_BYTES = SF3_H_SLOTS * SF3_H_ROW_BYTES;
+constexpr int SF3_POOL_BYTES = 2 * 112 * 128;
+constexpr int SF3_LDS_BYTES = SF3_IN_BYTES + SF3_H_BYTES + SF3_POOL_BYTES + SF_TAB_BYTES;
+#ifndef SF3_PRIO
+#define SF3_PRIO 2                                     // s_setprio of the service waves (0 = off; A/B knob)
+#endif
+constexpr int SF3_PACK_ITEMS = 8 * 56;                 // (input row, group of 4 pixels) of a pair's 8 new rows: 2 rounds of the service threads
+
+template <typename TIN> struct Sf3Load { typedef f32x4 type; };
+template <> struct Sf3Load<unsigned char> { typedef unsigned type; };
+
+template <int ET, typename TIN, bool C1>
+__global__ __launch_bounds__(SF3_THREADS) void stem_fused3_kernel(const TIN* __restrict__ x, const char* __restrict__ wpk,
+                                                                  const float* __restrict__ bias, __bf16* __restrict__ y,
+                                                                  int n_strips, int G, const float* __restrict__ u8_table,
+                                                                  const __bf16* __restrict__ c1_w, const float* __restrict__ c1_bias,
+                                                                  __bf16* __restrict__ y1
+#if defined(R50_STAMP)    // diagnostic build (scripts/stamp_stem.py): per-wave cycle sums, 8 slots per wave
+                                                                  , unsigned long long* dbg
+#endif
+                                                                  ) {
+#if defined(R50_STAMP)
+    struct { unsigned long long* dbg; } a{dbg};
+#endif
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_in = smem;
+    char* s_h = smem + SF3_IN_BYTES;
+    char* s_pool = smem + SF3_IN_BYTES + SF3_H_BYTES;
+    float* s_tab = reinterpret_cast<float*>(smem + SF3_IN_BYTES + SF3_H_BYTES + SF3_POOL_BYTES);
+    constexpr bool U8 = (sizeof(TIN) == 1);
+    typedef typename Sf3Load<TIN>::type ld_t;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool conv_wave = wave < 8;
+    const int rr = (wave >> 1) & 3, ch = wave & 1;     // conv waves: conv row of the pair, channel half; service waves: C1 pixel-block parity (rr & 1), channel half
+    const int sid = tid - 512;                         // service thread id (>= 0 on the service waves)
+
+    // the ring's border columns (wp 0..3 and 228..231 = the conv's horizontal zero padding) are written once: packing only writes wp 4..227
+    for (int c = tid; c < SF3_IN_SLOTS * 8; c += SF3_THREADS) {
+        const int slot = c >> 3, i = c & 7;
+        *reinterpret_cast<u32x2*>(s_in + (slot * STEM_WP + (i < 4 ? i : 224 + i)) * 8) = (u32x2){0u, 0u};
+    }
+    if constexpr (U8) {
+        for (int c = tid; c < 3 * 256; c += SF3_THREADS) s_tab[c] = u8_table[c];
+    }
+
+    // The two roles run the same strip / pair loops with the same barriers, each in its own branch: what one role keeps in registers
+    // across the loop (the conv weights; the prefetched pixels and the C1 weights) is not live in the other.
+    const int spi = 28 / G;                            // strips per image
+    const int kend = G + (C1 ? 2 : 1);                 // pooling runs one pair behind the conv, C1 two
+    R50_STAMP_DECL
+#if defined(R50_STAMP)
+    const unsigned long long st_c0 = __builtin_readcyclecounter();
+#endif
+    if (conv_wave) {
+        // ---- conv waves ----
+        // The image fragment is the MFMA's A operand (16 pixels x 32 K) and the weights its B operand (32 K x 16 channels), so an
+        // accumulator block holds, per lane, FOUR CONSECUTIVE PIXELS (4 fq + e) of one channel (fr): the 3-max over pixels is register-
+        // local (v_max3_f32) except for pixel 4 fq - 1, which comes from the lanes 16 below (ds_bpermute, one per block).  The two
+        // blocks of a wave carry channels 32 ch + 2 fr and + 2 fr + 1, so a pooled pixel's pair packs into one dword.  bias, the
+        // rounding and ReLU are monotone: max first, then they run on 2 pooled values instead of 4 (the same bits).
+        // Weight rows of the packed image are permuted (perm_row_to_cout in r50_abi.hip); channel c sits in row
+        // (c & ~31) | (c & 3) | ((c >> 3) & 3) << 2 | ((c >> 2) & 1) << 4.
+        // A row runs as two halves (pixel blocks 0-3, then 4-6), each K loop followed by its epilogue, and the two conv waves of a SIMD
+        // (waves w and w + 4) differ in priority: the favoured wave's K loop takes the MFMA pipe, the other one's epilogue (VALU, LDS
+        // round trips) runs underneath it, and the phases of the two stay interleaved from there on.
+        bf16x8 wreg[7][2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int cc = 32 * ch + 2 * fr + nb;
+            const int rho = (cc & ~31) | (cc & 3) | (((cc >> 3) & 3) << 2) | (((cc >> 2) & 1) << 4);
+#pragma unroll
+            for (int kh = 0; kh < 7; ++kh) wreg[kh][nb] = *reinterpret_cast<const bf16x8*>(wpk + kh * 4096 + rho * 64 + fq * 16);
+        }
+        const float b0 = bias[32 * ch + 2 * fr], b1 = bias[32 * ch + 2 * fr + 1];
+        const int rot_addr = ((lane + 48) & 63) << 2;   // ds_bpermute: read from the lane 16 below (mod 64)
+        const int x_lane = fr * 16 + fq * 16;
+        const int h_lane = 2 * fq * 128 + (((4 * ch + (fr >> 2)) ^ ((fq & 1) << 2)) << 4) + (fr & 3) * 4;
+        // conv row c (0 <= c < 112) of this wave's channel half: input rows 2c-3 .. 2c+3 from the ring -> horizontal 3-max, bias, ReLU
+        // -> h-pooled ring slot c % 10: pooled column q at q * 128, 16-B chunk g at g ^ (q & 2) * 2, channel pair inside the chunk.
+        // One 16-pixel block at a time: [fragments of block j+1 requested] [K loop of block j: 14 MFMAs] [block j's pixels 4 fq + 3 sent
+        // round the lanes] [epilogue of block j-1].  The MFMA bursts of a wave alternate with short VALU stretches, so the two conv waves
+        // of a SIMD fill each other's gaps all the way through the row, and what is left exposed at the end is one block's epilogue.
+        auto conv_row = [&](int c) {
+            int slot[7];
+#pragma unroll
+            for (int kh = 0; kh < 7; ++kh) slot[kh] = __builtin_amdgcn_readfirstlane((2 * c - 3 + kh + 2 * SF3_IN_SLOTS) % SF3_IN_SLOTS) * STEM_ROW_BYTES;
+            char* hrow = s_h + __builtin_amdgcn_readfirstlane((c + SF3_H_SLOTS) % SF3_H_SLOTS) * SF3_H_ROW_BYTES + h_lane;
+            bf16x8 xf[8][7];
+            f32x4 acc[7][2];
+            float rot[7][2];
+            auto request = [&](int j) {
+#pragma unroll
+                for (int kh = 0; kh < 7; ++kh) xf[j][kh] = *reinterpret_cast<const bf16x8*>(s_in + slot[kh] + x_lane + j * 256);
+            };
+            auto epilogue = [&](int j) {
+                float p0[2], p1[2];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const f32x4 a = acc[j][nb];
+                    // pixel 16 j + 4 fq - 1: from the lanes 16 below; on the lanes fq = 0 the previous block's lanes fq = 3 (the rotation wraps),
+                    // and left of the image the window's own pixel stands in for the -inf pad
+                    const float left = fq == 0 ? (j == 0 ? a[0] : rot[j > 0 ? j - 1 : 0][nb]) : rot[j][nb];
+                    p0[nb] = __builtin_fmaxf(__builtin_fmaxf(left, a[0]), a[1]);        // window centre 16 j + 4 fq     = pooled column 8 j + 2 fq
+                    p1[nb] = __builtin_fmaxf(__builtin_fmaxf(a[1], a[2]), a[3]);        // window centre 16 j + 4 fq + 2 = pooled column 8 j + 2 fq + 1
+                }
+                // pooled columns q = 8 j + 2 fq and q + 1: (q >> 1) & 1 is the same for both, one swizzle key (in h_lane) for both stores
+                *reinterpret_cast<unsigned*>(hrow + j * 8 * 128) = relu_bf16x2(pack2_e<ET>(p0[0] + b0, p0[1] + b1));
+                *reinterpret_cast<unsigned*>(hrow + j * 8 * 128 + 128) = relu_bf16x2(pack2_e<ET>(p1[0] + b0, p1[1] + b1));
+            };
+            request(0);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                if (j + 1 < 7) request(j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kh = 0; kh < 7; ++kh) {
+                    acc[j][0] = mfma_e<ET>(xf[j][kh], wreg[kh][0], acc[j][0]);
+                    acc[j][1] = mfma_e<ET>(xf[j][kh], wreg[kh][1], acc[j][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const float a3 = acc[j][nb][3];    // (a copy: __builtin_bit_cast of the vector-element lvalue reads element 0 with this hipcc)
+                    rot[j][nb] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(rot_addr, __builtin_bit_cast(int, a3)));
+                }
+                if (j > 0) epilogue(j - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            epilogue(6);
+        };
+        for (int strip = blockIdx.x; strip < n_strips; strip += gridDim.x) {
+            const int t0 = (strip % spi) * G;          // first pooled-row pair of the strip
+            __syncthreads();
+            for (int k = 0; k < kend; ++k) {
+                const int r0 = 2 * (t0 + k);           // first pooled row of the pair
+                R50_MARK(3)
+                __syncthreads();                       // pair k's input rows are packed (and the slots of the h-pooled rows it writes are free)
+                R50_MARK(0)
+                if (k < G) {
+                    if (k == 0 && r0 > 0 && rr == 3) conv_row(2 * r0 - 1);       // a strip that starts inside the image: the conv row it shares with the strip above
+                    conv_row(2 * r0 + rr);
+                    R50_MARK(1)
+                }
+            }
+        }
+    } else {
+        // ---- service waves ----
+        if (SF3_PRIO) __builtin_amdgcn_s_setprio(SF3_PRIO);    // short dependent chains (LDS round trips, 16 MFMAs): first in line when ready
+        // packing: item i of a pair's 8 new rows = (row i / 56, pixels 4 (i % 56) .. + 3); thread sid owns items sid and sid + 256 (the
+        // second one exists for sid < 192).  What does not change from pair to pair is computed once, here.
+        int pk_r[2], pk_src[2], pk_dst[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = sid + it * SF3_SVC < SF3_PACK_ITEMS ? sid + it * SF3_SVC : SF3_PACK_ITEMS - 1;    // (the idle slot loads a valid address and stores nothing)
+            const int r = item / 56, g = item - r * 56;
+            pk_r[it] = r;
+            pk_src[it] = 4 * g;
+            pk_dst[it] = (4 + 4 * g) * 8;
+        }
+        const bool pk_second = sid + SF3_SVC < SF3_PACK_ITEMS;
+        ld_t ld[2][3];
+        unsigned ld_ok = 0;                            // bit it: item `it` lies inside the image (rows above and below it pack as zeros)
+        int pk_off[2];                                 // byte offset of the item's 4 pixels from the first of the 8 rows
+#pragma unroll
+        for (int it = 0; it < 2; ++it) pk_off[it] = (pk_r[it] * 224 + pk_src[it]) * (int)sizeof(TIN);
+        auto load_rows = [&](int n, int first_row) {
+            const bool inside = first_row >= 0 && first_row + 8 <= 224;    // (uniform) all 8 rows inside the image: every pair but an image's first and last
+            const char* img = reinterpret_cast<const char*>(x + (size_t)n * 3 * 224 * 224 + (inside ? first_row * 224 : 0));
+            ld_ok = 3u;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                int off = pk_off[it];
+                if (!inside) {
+                    const int hi = first_row + pk_r[it];
+                    const bool ok = (unsigned)hi < 224u;
+                    if (!ok) ld_ok &= ~(1u << it);
+                    off = ((ok ? hi : 0) * 224 + pk_src[it]) * (int)sizeof(TIN);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    ld[it][cc] = *reinterpret_cast<const ld_t*>(img + (size_t)cc * 224 * 224 * sizeof(TIN) + (unsigned)off);
+            }
+        };
+        auto pack_rows = [&](int first_row) {          // registers -> ring slots row % 24, bf16 [wp][4]
+            const int s0 = __builtin_amdgcn_readfirstlane((first_row + 2 * SF3_IN_SLOTS) % SF3_IN_SLOTS);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                if (it == 0 || pk_second) {
+                    int slot = s0 + pk_r[it];
+                    slot = slot >= SF3_IN_SLOTS ? slot - SF3_IN_SLOTS : slot;
+                    const bool ok = (ld_ok >> it) & 1u;
+                    unsigned w[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v[3];
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) {
+                            if constexpr (U8) v[cc] = s_tab[cc * 256 + ((ld[it][cc] >> (8 * i)) & 255u)];
+                            else v[cc] = ld[it][cc][i];
+                        }
+                        w[2 * i] = pack2_e<ET>(v[0], v[1]);
+                        w[2 * i + 1] = pack2_e<ET>(v[2], 0.f);
+                    }
+                    if (!ok) {                         // a row above or below the image: the conv's zero padding
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) w[i] = 0u;
+                    }
+                    char* dst = s_in + slot * STEM_ROW_BYTES + pk_dst[it];
+                    *reinterpret_cast<u32x4*>(dst) = (u32x4){w[0], w[1], w[2], w[3]};
+                    *reinterpret_cast<u32x4*>(dst + 16) = (u32x4){w[4], w[5], w[6], w[7]};
+                }
+            }
+        };
+        // vertical 3-max: pooled row r0 = rows 2 r0 - 1, 2 r0, 2 r0 + 1 of the h-pooled ring, pooled row r0 + 1 = rows 2 r0 + 1 .. 2 r0 + 3
+        // (five reads give both).  Thread sid owns (column q, chunk g) = (sid >> 3, sid & 7) and (32 + (sid >> 3), sid & 7) (sid < 192).
+        int pl_off[2], pl_pool[2], pl_out[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q = (sid >> 3) + 32 * it < 56 ? (sid >> 3) + 32 * it : 55, g = sid & 7;
+            pl_off[it] = q * 128 + ((g ^ ((q & 2) << 1)) << 4);
+            pl_pool[it] = q * 128 + ((g ^ (q & 7)) << 4);          // s_pool: pixel pp = pr * 56 + q at pp * 128, chunk g at g ^ (pp & 7) (56 = 0 mod 8)
+            pl_out[it] = (q * 64 + g * 8) * 2;                      // bytes
+        }
+        const bool pl_second = (sid >> 3) + 32 < 56;
+        auto pool_pair = [&](int n, int r0, int pbuf) {
+            int hs[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) hs[i] = __builtin_amdgcn_readfirstlane((2 * r0 - 1 + i + SF3_H_SLOTS) % SF3_H_SLOTS) * SF3_H_ROW_BYTES;
+            u32x4 h[2][5];
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) h[it][i] = *reinterpret_cast<const u32x4*>(s_h + hs[i] + pl_off[it]);
+            char* yrow = reinterpret_cast<char*>(y + ((size_t)n * 56 + r0) * 56 * 64);
+            char* prow = s_pool + pbuf * (112 * 128);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                u32x4 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned top = r0 > 0 ? h[it][0][e] : 0u;                     // conv row -1 does not exist (values are >= +0: 0 is the pad)
+                    o0[e] = max_bf16x2_nonneg(max_bf16x2_nonneg(top, h[it][1][e]), h[it][2][e]);
+                    o1[e] = max_bf16x2_nonneg(max_bf16x2_nonneg(h[it][2][e], h[it][3][e]), h[it][4][e]);
+                }
+                if (it == 0 || pl_second) {
+                    *reinterpret_cast<u32x4*>(yrow + (unsigned)pl_out[it]) = o0;       // (uniform row pointer + a 32-bit lane offset: no 64-bit lane arithmetic)
+                    *reinterpret_cast<u32x4*>(yrow + (unsigned)(pl_out[it] + 56 * 128)) = o1;
+                    if constexpr (C1) {
+                        *reinterpret_cast<u32x4*>(prow + pl_pool[it]) = o0;
+                        *reinterpret_cast<u32x4*>(prow + 56 * 128 + pl_pool[it]) = o1;
+                    }
+                }
+            }
+        };
+        // layer1.0.conv1 on a pooled pair.  Accumulator block m, row 4 q + e is channel 32 ch + 8 q + 4 m + e (the igemm kernels'
+        // convention); pixel blocks rr & 1, + 2, + 4 (, + 6) of the pair's 7
+        bf16x8 a1[2][2];
+        float c1b[2][4];
+        int c1_in[2], c1_out = 0;
+        if constexpr (C1) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int chan = 32 * ch + 8 * (fr >> 2) + (fr & 3) + 4 * m;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) a1[m][kk] = *reinterpret_cast<const bf16x8*>(c1_w + chan * 64 + kk * 32 + fq * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c1b[m][e] = c1_bias[32 * ch + 8 * fq + 4 * m + e];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) c1_in[kk] = fr * 128 + (((4 * kk + fq) ^ (fr & 7)) << 4);     // pixel p = 16 jb + fr: p & 7 = fr & 7
+            c1_out = (fr * 64 + 32 * ch + 8 * fq) * 2;     // bytes
+        }
+        auto conv1_pair = [&](int n, int r0, int pbuf) {
+            if constexpr (C1) {
+                const int jb0 = rr & 1, nblk = 4 - jb0;            // blocks jb0, jb0 + 2, ..: 4 of them on the even waves, 3 on the odd
+                const char* prow = s_pool + pbuf * (112 * 128) + jb0 * 16 * 128;
+                char* out = reinterpret_cast<char*>(y1 + (((size_t)n * 56 + r0) * 56 + 16 * jb0) * 64);
+                bf16x8 xb[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) xb[i][kk] = *reinterpret_cast<const bf16x8*>(prow + (i < nblk ? i : 0) * 32 * 128 + c1_in[kk]);
+                f32x4 lo[4], hi[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lo[i] = (f32x4){c1b[0][0], c1b[0][1], c1b[0][2], c1b[0][3]};
+                    hi[i] = (f32x4){c1b[1][0], c1b[1][1], c1b[1][2], c1b[1][3]};
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        lo[i] = mfma_e<ET>(a1[0][kk], xb[i][kk], lo[i]);
+                        hi[i] = mfma_e<ET>(a1[1][kk], xb[i][kk], hi[i]);
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < nblk) {
+                        const u32x4 o = (u32x4){relu_bf16x2(pack2_e<ET>(lo[i][0], lo[i][1])), relu_bf16x2(pack2_e<ET>(lo[i][2], lo[i][3])),
+                                                relu_bf16x2(pack2_e<ET>(hi[i][0], hi[i][1])), relu_bf16x2(pack2_e<ET>(hi[i][2], hi[i][3]))};
+                        *reinterpret_cast<u32x4*>(out + (unsigned)(c1_out + i * 32 * 128)) = o;
+                    }
+                }
+            }
+        };
+        for (int strip = blockIdx.x; strip < n_strips; strip += gridDim.x) {
+            const int n = strip / spi;
+            const int t0 = (strip - n * spi) * G;
+            __syncthreads();                           // the previous strip is drained (first strip: borders and table are in place)
+            load_rows(n, 8 * t0 - 6);                  // rows 4 r0 - 6 .. 4 r0 + 1 (r0 = 2 t0): what a running strip would already hold
+            pack_rows(8 * t0 - 6);
+            load_rows(n, 8 * t0 + 2);                  // the first pair's own 8 rows
+            pack_rows(8 * t0 + 2);
+            if (G > 1) load_rows(n, 8 * t0 + 10);
+            for (int k = 0; k < kend; ++k) {
+                const int r0 = 2 * (t0 + k);           // first pooled row of the pair the conv waves work on
+                R50_MARK(4)
+                __syncthreads();                       // pair k-1's conv rows are complete, pair k-2's pooled rows too
+                R50_MARK(0)
+                if (k + 1 < G) {
+                    pack_rows(4 * r0 + 10);            // pair k+1's new rows 4 (r0 + 2) + 2 ..
+                    R50_MARK(1)
+                    if (k + 2 < G) load_rows(n, 4 * r0 + 18);
+                    R50_MARK(2)
+                }
+                if (k >= 1 && k <= G) pool_pair(n, r0 - 2, (k - 1) & 1);
+                R50_MARK(3)
+                if (C1 && k >= 2) conv1_pair(n, r0 - 4, k & 1);
+            }
+        }
+    }
+#if defined(R50_STAMP)
+    st_sum[6] = __builtin_readcyclecounter() - st_c0;
+#endif
+    R50_STAMP_FLUSH(12)
+}
+
 // ================================================================================================
 // Split-precision ("fp32x") variants of the non-GEMM kernels.  In this mode every activation travels
 // as a pair of bf16 tensors (head, tail) with head + tail ~ the fp32 value (16 mantissa bits), stored

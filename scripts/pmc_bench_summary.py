@@ -25,7 +25,7 @@ import sys
 
 
 def kernel_class(k: str):
-    if "igemm" in k or "conv3x3_c64" in k or "conv3x3_xres" in k or "conv3x3_s2" in k:
+    if "igemm" in k or "gemm8p" in k or "conv3x3_c64" in k or "conv3x3_xres" in k or "conv3x3_s2" in k:
         return "igemm"
     if "bneck_catchain" in k:
         return "bneck_catchain"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round refresh on the GPU box: full GPU test suite, default bench line, rocprofv3 kernel stats of the same command, per-layer
 # profile, PMC passes (HBM bytes per launch with the per-launch table, MFMA utilisation; full-batch launches only).  Outputs under
-# gpurun_out/; copy the summaries into profiles/ (r03_* names in profiles/README.md).
+# gpurun_out/; copy the summaries into profiles/ (r04_* names in profiles/README.md).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout -k 10 900 python3 -m pytest tests -m gpu -q > gpurun_out/t_final.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/t_final.log
