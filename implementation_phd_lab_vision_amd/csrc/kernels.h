@@ -4956,19 +4956,26 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fused2_kernel(const TIN* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused stem, role-split version (round 4): the arithmetic and the output bits of stem_fused2_kernel, but conv and everything else
-// run side by side instead of in turn.  12 waves: waves 0-7 are the conv waves (conv row rr = wave >> 1 of the pair, channel half
-// ch = wave & 1; two per SIMD), waves 8-11 the service waves (one per SIMD): they pack the NEXT pair's 8 input rows into the ring
-// (fp32 frames with 16-B loads, one thread = 4 pixels x 3 channels), pool the PREVIOUS pair's conv rows, store the pooled rows and
-// run layer1.0.conv1 on the pair before that.  One barrier per pair (stem_fused2: two, with the MFMA pipe idle during pack and pool).
-//   * conv1's weights live in registers (7 kernel rows x 2 fragment blocks x 4 registers per conv wave): the K loop reads only the
+// Fused stem, role-split version (round 4): fp32 / uint8 NCHW frames -> conv1 7x7 s2 + bias + ReLU -> MaxPool2d(3,2,1) -> (N,56,56,64)
+// NHWC, and (C1) layer1.0.conv1 of the pooled rows, in one launch; the arithmetic and the output bits of the strip kernel of round 3
+// (stem_fused2_kernel: all 8 waves pack, then all run MFMAs, then all pool -- two barriers per pair of pooled rows, the MFMA pipe idle
+// during two of the three phases; 149 us at batch 256), but conv and everything else run side by side.  A workgroup walks G
+// consecutive pooled-row pairs of ONE image (G = 28: the whole image) and keeps what consecutive pairs share in LDS rings.
+// 12 waves: waves 0-7 are the conv waves (conv row rr = wave >> 1 of the pair, channel half ch = wave & 1; two per SIMD), waves 8-11
+// the service waves (one per SIMD): they pack the NEXT pair's 8 input rows into the ring (16-B loads issued one pair ahead, one thread
+// = 4 pixels x 3 channels), pool the PREVIOUS pair's conv rows, store the pooled rows and run layer1.0.conv1 on the pair before that.
+// One barrier per pair.
+//   * conv1's weights live in registers (7 kernel rows x 2 channel blocks x 4 registers per conv wave): the K loop reads only the
 //     7 image fragments per kernel row from LDS, for 14 MFMAs;
-//   * the horizontal half of MaxPool2d(3,2,1) happens in the conv epilogue, in registers: a lane holds pixel wo = 16 j + fr of its
-//     8 channels, its neighbours wo -/+ 1 are the lanes fr -/+ 1 of the same 16-lane row (DPP row_shr / row_shl; pixel 16 j - 1 is
-//     lane 15 of block j - 1, row_ror), and only the even lanes (the window centres wo = 2 q) write: a conv row costs 56 x 128 B of
-//     LDS instead of 112 x 128 B, and the vertical half reads 3 values per output instead of 9;
+//   * the image fragment is the MFMA's A operand, the weights its B operand: an accumulator block then holds FOUR CONSECUTIVE PIXELS
+//     of one channel per lane, and the horizontal half of the 3x3 max-pool is register-local (v_max3_f32; one ds_bpermute per block
+//     for the pixel left of the lane's four).  Pooling before bias, rounding and ReLU (all monotone) gives the same bits and halves
+//     their work.  A conv row costs 56 x 128 B of LDS instead of 112 x 128 B, and the vertical half reads 5 values per 2 outputs;
 //   * rings: 24 input-row slots (the pair being read spans 15 rows, the 8 rows being written follow it), 10 h-pooled conv rows
 //     (5 being pooled + 4 being written), two pooled-pair buffers for C1.
+// Measured (profiles/r04_stem_experiments.txt): 93 us at batch 256 = 3.9 TB/s of frames + both outputs (the copy rate of this chip
+// is 5.3 TB/s); the conv waves' rows are bound by their own K loop (LDS fragment reads + MFMA at ~70 % of the pipe) -- deferring
+// epilogues, per-block software pipelining, opposite phases of the two conv waves of a SIMD and wave priorities all measured the same.
 // LDS: input ring 24 x 1,856 B | h-pooled conv ring 10 x 56 x 128 B | pooled pairs 2 x 14,336 B | u8 table 3,072 B = 147,968 B.
 // ------------------------------------------------------------------------------------------------
 constexpr int SF3_THREADS = 768;
@@ -5057,60 +5064,56 @@ __global__ __launch_bounds__(SF3_THREADS) void stem_fused3_kernel(const TIN* __r
         const int rot_addr = ((lane + 48) & 63) << 2;   // ds_bpermute: read from the lane 16 below (mod 64)
         const int x_lane = fr * 16 + fq * 16;
         const int h_lane = 2 * fq * 128 + (((4 * ch + (fr >> 2)) ^ ((fq & 1) << 2)) << 4) + (fr & 3) * 4;
-        // conv row c (0 <= c < 112) of this wave's channel half: input rows 2c-3 .. 2c+3 from the ring -> horizontal 3-max, bias, ReLU
-        // -> h-pooled ring slot c % 10: pooled column q at q * 128, 16-B chunk g at g ^ (q & 2) * 2, channel pair inside the chunk.
-        // One 16-pixel block at a time: [fragments of block j+1 requested] [K loop of block j: 14 MFMAs] [block j's pixels 4 fq + 3 sent
-        // round the lanes] [epilogue of block j-1].  The MFMA bursts of a wave alternate with short VALU stretches, so the two conv waves
-        // of a SIMD fill each other's gaps all the way through the row, and what is left exposed at the end is one block's epilogue.
+        // conv row c (0 <= c < 112) of this wave's channel half: input rows 2c-3 .. 2c+3 from the ring -> accumulators (K loop: 7 kernel
+        // rows x 7 pixel blocks x 2 channel blocks) -> every block's pixel 4 fq + 3 from the lanes 16 below (one LDS round trip for the row)
+        // -> horizontal 3-max, bias, ReLU -> h-pooled ring slot c % 10: pooled column q at q * 128, 16-B chunk g at g ^ (q & 2) * 2,
+        // channel pair inside the chunk.
         auto conv_row = [&](int c) {
             int slot[7];
 #pragma unroll
             for (int kh = 0; kh < 7; ++kh) slot[kh] = __builtin_amdgcn_readfirstlane((2 * c - 3 + kh + 2 * SF3_IN_SLOTS) % SF3_IN_SLOTS) * STEM_ROW_BYTES;
             char* hrow = s_h + __builtin_amdgcn_readfirstlane((c + SF3_H_SLOTS) % SF3_H_SLOTS) * SF3_H_ROW_BYTES + h_lane;
-            bf16x8 xf[8][7];
-            f32x4 acc[7][2];
-            float rot[7][2];
-            auto request = [&](int j) {
+            f32x4 acc[2][7];
 #pragma unroll
-                for (int kh = 0; kh < 7; ++kh) xf[j][kh] = *reinterpret_cast<const bf16x8*>(s_in + slot[kh] + x_lane + j * 256);
-            };
-            auto epilogue = [&](int j) {
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc[nb][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 7; ++kh) {
+                bf16x8 xf[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(s_in + slot[kh] + x_lane + j * 256);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) acc[nb][j] = mfma_e<ET>(xf[j], wreg[kh][nb], acc[nb][j]);
+            }
+            R50_MARK(1)
+            float rot[2][7];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const float a3 = acc[nb][j][3];    // (a copy: __builtin_bit_cast of the vector-element lvalue reads element 0 with this hipcc)
+                    rot[nb][j] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(rot_addr, __builtin_bit_cast(int, a3)));
+                }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
                 float p0[2], p1[2];
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
-                    const f32x4 a = acc[j][nb];
+                    const f32x4 a = acc[nb][j];
                     // pixel 16 j + 4 fq - 1: from the lanes 16 below; on the lanes fq = 0 the previous block's lanes fq = 3 (the rotation wraps),
                     // and left of the image the window's own pixel stands in for the -inf pad
-                    const float left = fq == 0 ? (j == 0 ? a[0] : rot[j > 0 ? j - 1 : 0][nb]) : rot[j][nb];
+                    const float left = fq == 0 ? (j == 0 ? a[0] : rot[nb][j > 0 ? j - 1 : 0]) : rot[nb][j];
                     p0[nb] = __builtin_fmaxf(__builtin_fmaxf(left, a[0]), a[1]);        // window centre 16 j + 4 fq     = pooled column 8 j + 2 fq
                     p1[nb] = __builtin_fmaxf(__builtin_fmaxf(a[1], a[2]), a[3]);        // window centre 16 j + 4 fq + 2 = pooled column 8 j + 2 fq + 1
                 }
                 // pooled columns q = 8 j + 2 fq and q + 1: (q >> 1) & 1 is the same for both, one swizzle key (in h_lane) for both stores
                 *reinterpret_cast<unsigned*>(hrow + j * 8 * 128) = relu_bf16x2(pack2_e<ET>(p0[0] + b0, p0[1] + b1));
                 *reinterpret_cast<unsigned*>(hrow + j * 8 * 128 + 128) = relu_bf16x2(pack2_e<ET>(p1[0] + b0, p1[1] + b1));
-            };
-            request(0);
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                if (j + 1 < 7) request(j + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kh = 0; kh < 7; ++kh) {
-                    acc[j][0] = mfma_e<ET>(xf[j][kh], wreg[kh][0], acc[j][0]);
-                    acc[j][1] = mfma_e<ET>(xf[j][kh], wreg[kh][1], acc[j][1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const float a3 = acc[j][nb][3];    // (a copy: __builtin_bit_cast of the vector-element lvalue reads element 0 with this hipcc)
-                    rot[j][nb] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(rot_addr, __builtin_bit_cast(int, a3)));
-                }
-                if (j > 0) epilogue(j - 1);
-                __builtin_amdgcn_sched_barrier(0);
             }
-            epilogue(6);
+            R50_MARK(2)
         };
         for (int strip = blockIdx.x; strip < n_strips; strip += gridDim.x) {
             const int t0 = (strip % spi) * G;          // first pooled-row pair of the strip
@@ -5123,7 +5126,6 @@ __global__ __launch_bounds__(SF3_THREADS) void stem_fused3_kernel(const TIN* __r
                 if (k < G) {
                     if (k == 0 && r0 > 0 && rr == 3) conv_row(2 * r0 - 1);       // a strip that starts inside the image: the conv row it shares with the strip above
                     conv_row(2 * r0 + rr);
-                    R50_MARK(1)
                 }
             }
         }

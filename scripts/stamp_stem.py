@@ -19,7 +19,7 @@ torch.cuda.synchronize()
 lib.r50_debug_buffer(None)
 t = dbg.double().cpu()
 pairs = 28 * max(1, n // 256)
-for name, arr, labels in (("conv waves", t[:, :8, :], ["barrier wait", "K loops (reads + MFMA)", "epilogues (pool, bias, ReLU, stores)", "loop overhead"]),
+for name, arr, labels in (("conv waves", t[:, :8, :], ["barrier wait", "K loop (reads + MFMA)", "epilogue (pool, bias, ReLU, stores)", "loop overhead"]),
                           ("service waves", t[:, 8:, :], ["barrier wait", "pack", "issue loads", "pool", "layer1.0.conv1"])):
     m = arr.mean(dim=(0, 1)); tot = m[:len(labels)].sum()
     print(f"{name}: stamped {tot:.0f} cycles per wave, {tot / pairs:.0f} per pair; kernel {m[6]:.0f} cycles")
