@@ -108,7 +108,7 @@ CLASS_LABELS = {
     "bneck_tail3": "bneck_tail3p_kernel: chained layer3 tails (conv3 + identity + ReLU + next conv1; layer3.5: conv3 alone)",
     "bneck_catchain": "bneck_catchain_kernel: layer2.0 conv3 + downsample + ReLU chained with layer2.1.conv1",
     "bneck_tail": "bneck_tail_kernel / bneck_tail2_kernel: fused layer1 / layer2 tails (not on the default path)",
-    "conv1": "stem_fused2_kernel: conv1 7x7 s2 + bn + ReLU + maxpool + layer1.0.conv1",
+    "conv1": "stem_fused3_kernel: frames -> conv1 7x7 s2 + bn + ReLU + maxpool + layer1.0.conv1",
     "avgpool": "avgpool_kernel",
 }
 TRAFFIC_KEYS = {"bneck_block2": "bneck_block"}       # class name in the committed PMC summary where it differs

@@ -4709,250 +4709,11 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const __bf16* __restrict__
     *reinterpret_cast<f32x4*>(o + 4) = (f32x4){s[4] * inv_hw, s[5] * inv_hw, s[6] * inv_hw, s[7] * inv_hw};
 }
 
-// ------------------------------------------------------------------------------------------------
-// Fused stem (bf16 mode): fp32 NCHW frame -> [pack to bf16 NHWC4 in LDS] -> conv1 7x7 s2 + bias + ReLU
-// -> [conv rows in LDS] -> MaxPool2d(3,2,1) -> (N,56,56,64) bf16 NHWC.  Replaces stem_pack + stem_conv +
-// maxpool: the 112x112x64 conv1 activation (1.6 MB/frame written and read back) never touches HBM and
-// the packed image is never materialised.
-// Workgroup = one image x 2 pooled rows (r0, r0+1): conv rows 2*r0-1 .. 2*r0+3 (5 waves, one conv row
-// each), input rows 4*r0-5 .. 4*r0+9 (15 rows; rows outside the image are zero = conv padding, conv
-// rows/cols outside 0..111 are skipped = -inf pool padding).
-// LDS: weights 28,672 B | input 15 x 1,856 B | conv out 5 x 112 x 128 B (16-B chunk c of pixel wo at c ^ (wo&7)).
-// ------------------------------------------------------------------------------------------------
-constexpr int SF_IN_ROWS = 15;
-constexpr int SF_CONV_ROWS = 5;
-constexpr int SF_IN_BYTES = SF_IN_ROWS * STEM_ROW_BYTES;
-constexpr int SF_OUT_BYTES = SF_CONV_ROWS * 112 * 128;
 constexpr int SF_TAB_BYTES = 3 * 256 * 4;               // uint8 frames: per-channel table u8 -> normalised fp32
-constexpr int SF_LDS_BYTES = STEM_W_BYTES + SF_IN_BYTES + SF_OUT_BYTES + SF_TAB_BYTES;
-constexpr int SF_THREADS = 512;                       // 8 waves: 5 of them run the MFMAs, all 8 pack and pool
-constexpr int SF_PACK_ROWS = 8;                       // rows per packing thread: threads [0,232) rows 0-7, [232,464) rows 8-14
 
 __device__ __forceinline__ unsigned max_bf16x2_nonneg(unsigned a, unsigned b) {   // both operands >= +0: integer order = float order
     typedef __attribute__((ext_vector_type(2))) short s16x2;
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fused stem, strip version: the same arithmetic as stem_fused_kernel (bit-identical output), but a workgroup walks G
-// consecutive pooled-row pairs of ONE image (G = 28: the whole image) and keeps what consecutive pairs share: the 7 input rows
-// and the conv row that the next pair needs again stay in LDS (rings of 16 input-row slots and 6 conv-row slots).  Per pair
-// that is 8 new input rows instead of 15 and 4 new conv rows instead of 5 -- and 4 rows x 2 channel halves are exactly 8 waves,
-// two per SIMD, where 5 row-waves left one SIMD with twice the MFMA work of the others.
-// C1: layer1.0.conv1 (1x1, 64 -> 64, + bias + ReLU) rides along: the pooled pair of rows (112 pixels x 64 channels) is also kept
-// in LDS as the B operand of a 64x64x112 GEMM whose A fragments (the whole weight matrix, 16 registers per lane) live in
-// registers; it runs one pair behind, at the start of the next pair's MFMA phase, so it needs no barrier of its own.  Same
-// accumulation order as the igemm launch it replaces (accumulator = bias, K-steps 0..31, 32..63): bit-identical y1.
-// LDS: weights 28,672 B | input ring 16 x 1,856 B | conv ring 5 x 112 x 128 B | pooled pair 14,336 B (C1) | u8 table 3,072 B = 147,456 B.
-// ------------------------------------------------------------------------------------------------
-constexpr int SF2_IN_SLOTS = 16;
-constexpr int SF2_OUT_SLOTS = 5;                      // 4 new conv rows per pair + the one the previous pair left
-constexpr int SF2_IN_BYTES = SF2_IN_SLOTS * STEM_ROW_BYTES;
-constexpr int SF2_OUT_BYTES = SF2_OUT_SLOTS * 112 * 128;
-constexpr int SF2_POOL_BYTES = 112 * 128;
-constexpr int SF2_LDS_BYTES = STEM_W_BYTES + SF2_IN_BYTES + SF2_OUT_BYTES + SF2_POOL_BYTES + SF_TAB_BYTES;
-constexpr int SF2_PACK_ROWS = 4;                      // rows per packing thread and round: threads [0,232) rows 0-3, [232,464) rows 4-7
-
-template <int ET, typename TIN, bool C1>
-__global__ __launch_bounds__(SF_THREADS) void stem_fused2_kernel(const TIN* __restrict__ x, const char* __restrict__ wpk,
-                                                                 const float* __restrict__ bias, __bf16* __restrict__ y,
-                                                                 int n_strips, int G, const float* __restrict__ u8_table,
-                                                                 const __bf16* __restrict__ c1_w, const float* __restrict__ c1_bias,
-                                                                 __bf16* __restrict__ y1) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_w = smem;
-    char* s_in = smem + STEM_W_BYTES;
-    char* s_out = smem + STEM_W_BYTES + SF2_IN_BYTES;
-    char* s_pool = smem + STEM_W_BYTES + SF2_IN_BYTES + SF2_OUT_BYTES;
-    float* s_tab = reinterpret_cast<float*>(smem + STEM_W_BYTES + SF2_IN_BYTES + SF2_OUT_BYTES + SF2_POOL_BYTES);
-    constexpr bool U8 = (sizeof(TIN) == 1);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
-    const int rr = wave >> 1, ch = wave & 1;           // conv row of the round, channel half (couts 32*ch .. 32*ch+31)
-
-    // weight rows are 64 B (32 K values): chunk q of row r of a 16-row fragment block is stored at q ^ {0,2,3,1}[(r >> 2) & 3], which spreads
-    // the 16 lanes of every ds_read_b128 group over the 16 (bank quadrant, chunk) pairs -- stored linearly, rows r and r + 12 (same
-    // quadrant, same chunk) made every weight-fragment read a 2-way conflict: 26 % of this kernel's LDS cycles
-    for (int c = tid; c < STEM_W_BYTES / 16; c += SF_THREADS) {
-        const int row = c >> 2, q = c & 3, key = (0x78 >> (((row >> 2) & 3) * 2)) & 3;       // {0,2,3,1} packed two bits each = 0b01'11'10'00
-        *reinterpret_cast<u32x4*>(s_w + (row * 4 + (q ^ key)) * 16) = *reinterpret_cast<const u32x4*>(wpk + c * 16);
-    }
-    if constexpr (U8) {
-        for (int c = tid; c < 3 * 256; c += SF_THREADS) s_tab[c] = u8_table[c];
-    }
-
-    const int p_half = tid >= STEM_WP ? 1 : 0;
-    const int p_wp = tid - p_half * STEM_WP;
-    const bool p_active = tid < 2 * STEM_WP;
-    const bool p_col_ok = p_active && (unsigned)(p_wp - 4) < 224u;
-    float pc[SF2_PACK_ROWS][3];
-    auto load_rows = [&](int n, int first_row) {       // input rows first_row .. first_row + 7 of image n -> registers
-        const int in0 = first_row + p_half * SF2_PACK_ROWS;
-        const TIN* base = x + (size_t)n * 3 * 224 * 224 + (p_col_ok ? p_wp - 4 : 0);
-#pragma unroll
-        for (int r = 0; r < SF2_PACK_ROWS; ++r) {
-            const int hi = in0 + r;
-            const bool ok = p_col_ok && (unsigned)hi < 224u;
-            const TIN* p = base + (ok ? hi * 224 : 0);
-            if constexpr (U8) {
-                pc[r][0] = ok ? (float)p[0] : -1.f;
-                pc[r][1] = ok ? (float)p[224 * 224] : -1.f;
-                pc[r][2] = ok ? (float)p[2 * 224 * 224] : -1.f;
-            } else {
-                pc[r][0] = ok ? frame_value(p, 0) : 0.f;
-                pc[r][1] = ok ? frame_value(p + 224 * 224, 1) : 0.f;
-                pc[r][2] = ok ? frame_value(p + 2 * 224 * 224, 2) : 0.f;
-            }
-        }
-    };
-    auto sample = [&](float v, int c) -> float {
-        if constexpr (U8) return v < 0.f ? 0.f : s_tab[c * 256 + (int)v];
-        else return v;
-    };
-    auto store_rows = [&](int first_row) {             // registers -> ring slots (row + 32) & 15, bf16 [wp][4]
-        if (p_active) {
-#pragma unroll
-            for (int r = 0; r < SF2_PACK_ROWS; ++r) {
-                const int slot = (first_row + p_half * SF2_PACK_ROWS + r + 32) & (SF2_IN_SLOTS - 1);
-                *reinterpret_cast<u32x2*>(s_in + (slot * STEM_WP + p_wp) * 8) =
-                    (u32x2){pack2_e<ET>(sample(pc[r][0], 0), sample(pc[r][1], 1)), pack2_e<ET>(sample(pc[r][2], 2), 0.f)};
-            }
-        }
-    };
-    // conv row c (0 <= c < 112) of this wave's channel half: input rows 2c-3 .. 2c+3 from the ring -> conv ring slot c % 6
-    auto conv_row = [&](int c) {
-        f32x4 acc[2][7];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int j = 0; j < 7; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int w_frag = fr * 64 + ((fq ^ ((0x78 >> (((fr >> 2) & 3) * 2)) & 3)) << 4);
-        const int x_lane = fr * 16 + fq * 16;
-#pragma unroll
-        for (int kh = 0; kh < 7; ++kh) {
-            const int slot = __builtin_amdgcn_readfirstlane((2 * c - 3 + kh + 32) & (SF2_IN_SLOTS - 1));
-            bf16x8 wf[2], xf[7];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) wf[m] = *reinterpret_cast<const bf16x8*>(s_w + kh * 4096 + (2 * ch + m) * 1024 + w_frag);
-#pragma unroll
-            for (int j = 0; j < 7; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(s_in + slot * STEM_ROW_BYTES + x_lane + j * 256);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int j = 0; j < 7; ++j) acc[m][j] = mfma_e<ET>(wf[m], xf[j], acc[m][j]);
-        }
-        const int oslot = __builtin_amdgcn_readfirstlane(c % SF2_OUT_SLOTS);
-        const int cout = 32 * ch + 8 * fq;
-        const f32x4 b_lo = *reinterpret_cast<const f32x4*>(bias + cout);
-        const f32x4 b_hi = *reinterpret_cast<const f32x4*>(bias + cout + 4);
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int wo = 16 * j + fr;
-            u32x4 out;
-            out[0] = relu_bf16x2(pack2_e<ET>(acc[0][j][0] + b_lo[0], acc[0][j][1] + b_lo[1]));
-            out[1] = relu_bf16x2(pack2_e<ET>(acc[0][j][2] + b_lo[2], acc[0][j][3] + b_lo[3]));
-            out[2] = relu_bf16x2(pack2_e<ET>(acc[1][j][0] + b_hi[0], acc[1][j][1] + b_hi[1]));
-            out[3] = relu_bf16x2(pack2_e<ET>(acc[1][j][2] + b_hi[2], acc[1][j][3] + b_hi[3]));
-            *reinterpret_cast<u32x4*>(s_out + (oslot * 112 + wo) * 128 + (((4 * ch + fq) ^ (wo & 7)) << 4)) = out;
-        }
-    };
-
-    // layer1.0.conv1: this wave's 32 output channels x K = 64 as A fragments.  Accumulator block m, row 4 q + e is channel
-    // 32 ch + 8 q + 4 m + e (the igemm kernels' convention: a lane ends up with 8 consecutive channels of its pixel)
-    bf16x8 a1[2][2];
-    float c1b[2][4];
-    if constexpr (C1) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int chan = 32 * ch + 8 * (fr >> 2) + (fr & 3) + 4 * m;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) a1[m][kk] = *reinterpret_cast<const bf16x8*>(c1_w + chan * 64 + kk * 32 + fq * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) c1b[m][e] = c1_bias[32 * ch + 8 * fq + 4 * m + e];
-        }
-    }
-    auto conv1_pair = [&](int n, int r0) {              // y1 rows r0, r0 + 1 of image n from the pooled pair in s_pool
-        if constexpr (C1) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int jb = rr + 4 * half;          // pixel blocks {rr, rr + 4}; 7 blocks in all
-                if (jb < 7) {
-                    const int p = 16 * jb + fr;
-                    f32x4 lo = (f32x4){c1b[0][0], c1b[0][1], c1b[0][2], c1b[0][3]};
-                    f32x4 hi = (f32x4){c1b[1][0], c1b[1][1], c1b[1][2], c1b[1][3]};
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(s_pool + p * 128 + (((4 * kk + fq) ^ (p & 7)) << 4));
-                        lo = mfma_e<ET>(a1[0][kk], xb, lo);
-                        hi = mfma_e<ET>(a1[1][kk], xb, hi);
-                    }
-                    u32x4 o = (u32x4){relu_bf16x2(pack2_e<ET>(lo[0], lo[1])), relu_bf16x2(pack2_e<ET>(lo[2], lo[3])),
-                                      relu_bf16x2(pack2_e<ET>(hi[0], hi[1])), relu_bf16x2(pack2_e<ET>(hi[2], hi[3]))};
-                    *reinterpret_cast<u32x4*>(y1 + (((size_t)n * 56 + r0) * 56 + p) * 64 + 32 * ch + 8 * fq) = o;
-                }
-            }
-        }
-    };
-
-    const int spi = 28 / G;                            // strips per image
-    for (int strip = blockIdx.x; strip < n_strips; strip += gridDim.x) {
-        const int n = strip / spi;
-        const int t0 = (strip - n * spi) * G;          // first pooled-row pair of the strip
-        __syncthreads();                               // the previous strip's readers of both rings are done (and s_w is staged)
-        load_rows(n, 8 * t0 - 6);                      // rows 4 r0 - 6 .. 4 r0 + 1 (r0 = 2 t0): what a running strip would already hold
-        store_rows(8 * t0 - 6);
-        load_rows(n, 8 * t0 + 2);
-        for (int ti = 0; ti < G; ++ti) {
-            const int r0 = 2 * (t0 + ti);              // first pooled row of the pair
-            store_rows(4 * r0 + 2);                    // the pair's 8 new input rows 4 r0 + 2 .. 4 r0 + 9
-            __syncthreads();                           // input ring ready; the previous pair's pooling is finished
-            if (ti + 1 < G) load_rows(n, 4 * r0 + 10);
-            if (ti > 0) conv1_pair(n, r0 - 2);         // the previous pair's pooled rows are complete in s_pool
-            if (ti == 0 && r0 > 0 && rr == 3) conv_row(2 * r0 - 1);       // a strip that starts inside the image: the shared conv row
-            conv_row(2 * r0 + rr);                     // the pair's 4 new conv rows 2 r0 .. 2 r0 + 3
-            __syncthreads();                           // conv ring complete
-            if (tid < 56 * 8) {
-                const int g = tid & 7, q = tid >> 3;
-                u32x4 hrow[SF_CONV_ROWS];
-#pragma unroll
-                for (int lrow = 0; lrow < SF_CONV_ROWS; ++lrow) {
-                    u32x4 h = (u32x4){0u, 0u, 0u, 0u};
-                    const int c = 2 * r0 - 1 + lrow;
-                    if (c >= 0) {                      // c <= 111 always
-                        const int oslot = c % SF2_OUT_SLOTS;
-#pragma unroll
-                        for (int dw = 0; dw < 3; ++dw) {
-                            const int wo = 2 * q - 1 + dw;
-                            if (wo >= 0) {
-                                const u32x4 v = *reinterpret_cast<const u32x4*>(s_out + (oslot * 112 + wo) * 128 + ((g ^ (wo & 7)) << 4));
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) h[e] = max_bf16x2_nonneg(h[e], v[e]);
-                            }
-                        }
-                    }
-                    hrow[lrow] = h;
-                }
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    u32x4 out;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        out[e] = max_bf16x2_nonneg(max_bf16x2_nonneg(hrow[2 * pr][e], hrow[2 * pr + 1][e]), hrow[2 * pr + 2][e]);
-                    *reinterpret_cast<u32x4*>(y + (((size_t)n * 56 + r0 + pr) * 56 + q) * 64 + g * 8) = out;
-                    if constexpr (C1) {
-                        const int pp = pr * 56 + q;
-                        *reinterpret_cast<u32x4*>(s_pool + pp * 128 + ((g ^ (pp & 7)) << 4)) = out;
-                    }
-                }
-            }
-        }
-        if constexpr (C1) {                            // the strip's last pair
-            __syncthreads();
-            conv1_pair(n, 2 * (t0 + G - 1));
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

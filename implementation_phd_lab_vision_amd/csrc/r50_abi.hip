@@ -1025,12 +1025,11 @@ hipError_t launch_stem_conv(const void* xp, const void* wpk, const float* bias, 
                        (const char*)xp, (const char*)wpk, bias, (__bf16*)y);
     return hipGetLastError();
 }
-// fused stem (stem_fused2_kernel, strip version): strip length 0 = chosen from the batch, 1/2/4/7/14/28 = that many pooled-row pairs per strip.
-// r50_set_option("stem_strip") or R50_STEM_STRIP in the environment (A/B).  (The per-pair kernel of round 1, stem_fused_kernel, was removed in round 4.)
+// fused stem (stem_fused3_kernel): a workgroup walks a strip of G consecutive pooled-row pairs of one image.  Strip length 0 = chosen from the
+// batch, 1/2/4/7/14/28 = that many pairs per strip: r50_set_option("stem_strip") or R50_STEM_STRIP in the environment (A/B).
+// (Removed in round 4: the per-pair kernel of round 1 and the strip kernel of rounds 2-3, whose phases ran in turn.)
 static int g_stem_strip = [] { const char* v = std::getenv("R50_STEM_STRIP"); const int g = v ? std::atoi(v) : 0; return g > 0 && 28 % g == 0 ? g : 0; }();
 bool stem_strip_enabled() { return true; }
-// 3 = stem_fused3_kernel (conv and pack/pool side by side), 2 = stem_fused2_kernel (in turn); same bits.  R50_STEM_VARIANT / option "stem_variant"
-static int g_stem_variant = [] { const char* v = std::getenv("R50_STEM_VARIANT"); return v && std::atoi(v) == 2 ? 2 : 3; }();
 // c1_w / c1_bias / y1 non-null: layer1.0.conv1 (+ bias + ReLU) of the pooled output into y1 in the same launch
 template <typename TIN>
 hipError_t launch_stem_fused(const TIN* x, const void* wpk, const float* bias, void* y, int n, hipStream_t s,
@@ -1042,8 +1041,7 @@ hipError_t launch_stem_fused(const TIN* x, const void* wpk, const float* bias, v
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
         g_num_cus = cu_budget(prop.multiProcessorCount);
     }
-    // a workgroup walks G consecutive pooled-row pairs of one image; G = the longest strip that still gives the chip ~200 workgroups
-    // (28 = the whole image from batch 200 up)
+    // G = the longest strip that still gives the chip ~200 workgroups (28 = the whole image from batch 200 up)
     int G = 1;
     if (g_stem_strip > 0) G = g_stem_strip;
     else
@@ -1051,29 +1049,20 @@ hipError_t launch_stem_fused(const TIN* x, const void* wpk, const float* bias, v
             if (n * (28 / cand) >= 200) { G = cand; break; }
     const bool c1 = c1_w && c1_bias && y1;
     const int strips = n * (28 / G);
-    const int grid2 = strips < g_num_cus ? strips : g_num_cus;
-    if (g_stem_variant == 3) {
-        // 16-B (fp32) / 4-B (uint8) loads of 4 pixels: image rows start at multiples of 896 / 224 bytes from the frame pointer
-        if (reinterpret_cast<uintptr_t>(x) & (sizeof(TIN) == 1 ? 3u : 15u)) return hipErrorInvalidValue;
-        auto kern3 = c1 ? (et == 1 ? stem_fused3_kernel<1, TIN, true> : stem_fused3_kernel<0, TIN, true>)
-                        : (et == 1 ? stem_fused3_kernel<1, TIN, false> : stem_fused3_kernel<0, TIN, false>);
-        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, SF3_LDS_BYTES);
-        if (e3 != hipSuccess) return e3;
-#if defined(R50_STAMP)
-        hipLaunchKernelGGL(kern3, dim3(grid2), dim3(SF3_THREADS), SF3_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, strips, G, u8_table,
-                           (const __bf16*)c1_w, c1_bias, (__bf16*)y1, g_dbg);
-#else
-        hipLaunchKernelGGL(kern3, dim3(grid2), dim3(SF3_THREADS), SF3_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, strips, G, u8_table,
-                           (const __bf16*)c1_w, c1_bias, (__bf16*)y1);
-#endif
-        return hipGetLastError();
-    }
-    auto kern2 = c1 ? (et == 1 ? stem_fused2_kernel<1, TIN, true> : stem_fused2_kernel<0, TIN, true>)
-                    : (et == 1 ? stem_fused2_kernel<1, TIN, false> : stem_fused2_kernel<0, TIN, false>);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, SF2_LDS_BYTES);
+    const int grid = strips < g_num_cus ? strips : g_num_cus;
+    // 16-B (fp32) / 4-B (uint8) loads of 4 pixels: image rows start at multiples of 896 / 224 bytes from the frame pointer
+    if (reinterpret_cast<uintptr_t>(x) & (sizeof(TIN) == 1 ? 3u : 15u)) return hipErrorInvalidValue;
+    auto kern = c1 ? (et == 1 ? stem_fused3_kernel<1, TIN, true> : stem_fused3_kernel<0, TIN, true>)
+                   : (et == 1 ? stem_fused3_kernel<1, TIN, false> : stem_fused3_kernel<0, TIN, false>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SF3_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern2, dim3(grid2), dim3(SF_THREADS), SF2_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, strips, G, u8_table,
+#if defined(R50_STAMP)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SF3_THREADS), SF3_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, strips, G, u8_table,
+                       (const __bf16*)c1_w, c1_bias, (__bf16*)y1, g_dbg);
+#else
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SF3_THREADS), SF3_LDS_BYTES, s, x, (const char*)wpk, bias, (__bf16*)y, strips, G, u8_table,
                        (const __bf16*)c1_w, c1_bias, (__bf16*)y1);
+#endif
     return hipGetLastError();
 }
 template <typename TIN>
@@ -1926,7 +1915,6 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
         if (!(value == 0 || (value > 0 && 28 % value == 0))) return fail(h, R50_ERR_INVALID, "stem_strip must be 0 or a divisor of 28");
         g_stem_strip = (int)value;
     }
-    else if (k == "stem_variant") { if (value != 2 && value != 3) return fail(h, R50_ERR_INVALID, "stem_variant must be 2 or 3"); g_stem_variant = (int)value; }   // process-wide A/B knob
     else if (k == "overlap_ds") h->overlap_ds = value ? 1 : 0;
     else if (k == "streams") { if (value < 1 || value > 4) return fail(h, R50_ERR_INVALID, "streams must be in [1,4]"); h->n_streams = (int)value; }
     else if (k == "inplace_out") h->inplace_out = value ? 1 : 0;
@@ -1961,7 +1949,6 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "fuse_stem_c1") *value = h->fuse_stem_c1;
     else if (k == "fuse_ds_cat") *value = h->fuse_ds_cat;
     else if (k == "stem_strip") *value = g_stem_strip;
-    else if (k == "stem_variant") *value = g_stem_variant;
     else if (k == "overlap_ds") *value = h->overlap_ds;
     else if (k == "max_batch") *value = h->max_batch;
     else if (k == "workspace_bytes") *value = (int64_t)(5 * h->buf_bytes + (size_t)h->max_batch * STEM_HP * STEM_WP * 8);

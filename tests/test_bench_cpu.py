@@ -73,7 +73,7 @@ def test_pmc_summary_counts_full_batch_launches_only(tmp_path):
     sys.path.insert(0, str(ROOT / "scripts"))
     import io
     import pmc_bench_summary as P
-    stem, conv = "void stem_fused2_kernel<0>(float const*)", "void igemm_ws_kernel<0, 128, 224, 4, 2, 4, 3>(ConvArgs)"
+    stem, conv = "void stem_fused3_kernel<0>(float const*)", "void igemm_ws_kernel<0, 128, 224, 4, 2, 4, 3>(ConvArgs)"
     fetch, write = [], []
     did = 0
     for f in range(7):                                   # 7 full-batch forwards: stem, conv, conv (two layers on one kernel, same grid)
