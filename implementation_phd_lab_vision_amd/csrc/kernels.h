@@ -4736,7 +4736,9 @@ __device__ __forceinline__ unsigned max_bf16x2_nonneg(unsigned a, unsigned b) { 
 //     (5 being pooled + 4 being written), two pooled-pair buffers for C1.
 // Measured (profiles/r04_stem_experiments.txt): 93 us at batch 256 = 3.9 TB/s of frames + both outputs (the copy rate of this chip
 // is 5.3 TB/s); the conv waves' rows are bound by their own K loop (LDS fragment reads + MFMA at ~70 % of the pipe) -- deferring
-// epilogues, per-block software pipelining, opposite phases of the two conv waves of a SIMD and wave priorities all measured the same.
+// epilogues, per-block software pipelining, opposite phases of the two conv waves of a SIMD and wave priorities all measured the same;
+// so did 4 conv waves with two conv rows each (63 fragment reads per two rows instead of 98, fragments double-buffered explicitly: 196
+// MFMAs in 4.2 k cycles -- ONE wave per SIMD issues an MFMA every ~21 cycles, two every ~18, as scripts/micro/mfma_peak.hip had said).
 // LDS: input ring 24 x 1,856 B | h-pooled conv ring 10 x 56 x 128 B | pooled pairs 2 x 14,336 B | u8 table 3,072 B = 147,968 B.
 // ------------------------------------------------------------------------------------------------
 constexpr int SF3_THREADS = 768;
@@ -4748,9 +4750,6 @@ constexpr int SF3_IN_BYTES = SF3_IN_SLOTS * STEM_ROW_BYTES;
 constexpr int SF3_H_BYTES = SF3_H_SLOTS * SF3_H_ROW_BYTES;
 constexpr int SF3_POOL_BYTES = 2 * 112 * 128;
 constexpr int SF3_LDS_BYTES = SF3_IN_BYTES + SF3_H_BYTES + SF3_POOL_BYTES + SF_TAB_BYTES;
-#ifndef SF3_PRIO
-#define SF3_PRIO 2                                     // s_setprio of the service waves (0 = off; A/B knob)
-#endif
 constexpr int SF3_PACK_ITEMS = 8 * 56;                 // (input row, group of 4 pixels) of a pair's 8 new rows: 2 rounds of the service threads
 
 template <typename TIN> struct Sf3Load { typedef f32x4 type; };
@@ -4892,7 +4891,6 @@ __global__ __launch_bounds__(SF3_THREADS) void stem_fused3_kernel(const TIN* __r
         }
     } else {
         // ---- service waves ----
-        if (SF3_PRIO) __builtin_amdgcn_s_setprio(SF3_PRIO);    // short dependent chains (LDS round trips, 16 MFMAs): first in line when ready
         // packing: item i of a pair's 8 new rows = (row i / 56, pixels 4 (i % 56) .. + 3); thread sid owns items sid and sid + 256 (the
         // second one exists for sid < 192).  What does not change from pair to pair is computed once, here.
         int pk_r[2], pk_src[2], pk_dst[2];
