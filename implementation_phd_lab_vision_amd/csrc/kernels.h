@@ -184,6 +184,9 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv d) {
     return d.mul == 0u ? n : (__umulhi(n, d.mul) >> d.shr);
 }
 
+#ifndef XCD_REMAP
+#define XCD_REMAP 1                                    // input-resident 3x3 kernels (A/B knob)
+#endif
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     // Blocks b and b+8 share an XCD (observed round-robin; speed only, never correctness).  Give each
     // XCD a contiguous run of logical ids so tiles sharing an X panel hit the same L2.
@@ -1404,7 +1407,9 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grid = gridDim.x;
-    const int first = blockIdx.x;
+    // XCD_REMAP: the workgroups of one XCD (ids b, b + 8, ..) take a contiguous run of tile ids, so the cout tiles of a pixel tile share one L2
+    // (the input tile is fetched once instead of once per cout tile)
+    const int first = XCD_REMAP ? xcd_remap(blockIdx.x, grid) : (int)blockIdx.x;
     const int nct = a.Cout / BC;
     const int n_tiles = a.n_blocks;                                   // pixel tiles x cout tiles (cout tile fastest)
     const int my_tiles = (n_tiles - first + grid - 1) / grid;
@@ -1780,7 +1785,7 @@ __global__ __launch_bounds__(768) void conv3x3_s2_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grid = gridDim.x, first = blockIdx.x;
+    const int grid = gridDim.x, first = XCD_REMAP ? xcd_remap(blockIdx.x, grid) : (int)blockIdx.x;
     const int nct = a.Cout / BC;
     const int n_tiles = a.n_blocks;                                   // pixel tiles x cout tiles (cout tile fastest)
     const int my_tiles = (n_tiles - first + grid - 1) / grid;
