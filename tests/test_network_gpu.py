@@ -439,7 +439,7 @@ def test_fp8_mode_is_batch_independent_and_needs_scales(setup_fp8):
 
 
 def test_layer3_chained_tail_is_bit_identical_to_separate_launches(setup):
-    """layer3.1-.4: conv3 + identity + ReLU chained with the next block's conv1 in one launch (bneck_tail3_kernel) -- same features,
+    """layer3.1-.4: conv3 + identity + ReLU chained with the next block's conv1 in one launch (bneck_tail3p_kernel) -- same features,
     bit for bit, as the two igemm launches per block it replaces; and the taps it produces match too."""
     bb, x, *_ = setup
     xd = x.to("cuda:0")
