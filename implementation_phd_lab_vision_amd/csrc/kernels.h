@@ -215,13 +215,7 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned v) {   // max(x, 0) on 
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
 }
 
-// Cache-policy bits (aux) of the igemm epilogue's residual loads and output stores: 0 = default; 2 = nt.  A/B knobs (scripts/build_variant.sh).
-#ifndef R50_RES_AUX
-#define R50_RES_AUX 0
-#endif
-#ifndef R50_ST_AUX
-#define R50_ST_AUX 0
-#endif
+// (nt cache policies on the epilogues' residual loads and output stores were measured slower: profiles/r03_tail_cache_policy_ab.txt)
 constexpr unsigned kOobOffset = 0x80000000u;
 
 template <int ET, int BC, int BP, int WC, int WP, int NSTAGE, bool SPLIT = false>
@@ -368,7 +362,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
                 acc[2 * t][j] = b_lo;
                 acc[2 * t + 1][j] = b_hi;
                 if constexpr (PREFETCH_RES) if (has_res)     // row displacement in voffset: soffset is not part of the range check
-                    res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, R50_RES_AUX);
+                    res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, 0);
             }
         }
     };
@@ -425,7 +419,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
                     if (has_res) {
                         u32x4 r;
                         if constexpr (PREFETCH_RES) r = res_reg[t][j];
-                        else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, 0, R50_RES_AUX);
+                        else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, 0, 0);
                         lo[0] += unpack_lo_e<ET>(r[0]); lo[1] += unpack_hi_e<ET>(r[0]);
                         lo[2] += unpack_lo_e<ET>(r[1]); lo[3] += unpack_hi_e<ET>(r[1]);
                         hi[0] += unpack_lo_e<ET>(r[2]); hi[1] += unpack_hi_e<ET>(r[2]);
@@ -437,7 +431,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_bf16_kernel(const ConvArgs
 #pragma unroll
                         for (int e = 0; e < 4; ++e) out[e] = relu_bf16x2(out[e]);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, R50_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, 0);
                 } else {
                     // split mode: values travel as bf16 pairs (head, tail) with head + tail ~ fp32 (16 mantissa bits)
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -601,13 +595,8 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
             const int tap = __builtin_amdgcn_readfirstlane(i_tap);
 #pragma unroll
             for (int i = 0; i < WROWS; ++i)
-#if defined(R50_ABLATE_OOB) && (R50_ABLATE_OOB & 2)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (LDS_AS void*)(sbase + i * PASS_BYTES + lw * 1024), 16,
-                                                         kOobOffset | (w_voff[i] & 0u), wofs, 0, 0);
-#else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (LDS_AS void*)(sbase + i * PASS_BYTES + lw * 1024), 16, w_voff[i],
                                                          wofs, 0, 0);
-#endif
             if (i_cc >= a.cc1) {                           // second K source (uniform): its own descriptor, pixels and chunk offset
                 const int x2ofs = __builtin_amdgcn_readfirstlane((i_cc - a.cc1) * 128);
 #pragma unroll
@@ -624,11 +613,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
             } else {
 #pragma unroll
             for (int i = 0; i < XROWS; ++i) {
-#if defined(R50_ABLATE_OOB) && (R50_ABLATE_OOB & 1)     // diagnostic: every X DMA zero-fills (no L2 traffic for X)
-                const unsigned voff = kOobOffset | (x_mask[i] & 0u);
-#else
                 const unsigned voff = ((x_mask[i] >> tap) & 1u) ? x_voff[i] : kOobOffset;
-#endif
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void*)(sbase + BC * 128 + i * PASS_BYTES + lw * 1024), 16,
                                                          voff, xofs, 0, 0);
             }
@@ -662,11 +647,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
             if (g + D < total) stage_issue();
             R50_MARK(0)                                  // DMA issue
             // stages issued so far: 0 .. min(g+D, total-1); stage g+1 must be complete
-#if defined(R50_ABLATE_WS) && (R50_ABLATE_WS & 8)
-            if (false) {
-#else
             if (g + D < total) {
-#endif
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LOADS_PER_STAGE) : "memory");
             } else if (D >= 3 && g + D - 1 < total) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D >= 3 ? D - 2 : 0) * LOADS_PER_STAGE) : "memory");
@@ -729,7 +710,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
                             const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_r, y_voff + j * y_rowstep + 32 * t, 0, 0);
                             res_reg[t][j] = (u32x4){r2[0], r2[1], 0u, 0u};
                         } else {
-                            res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, R50_RES_AUX);
+                            res_reg[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, 0);
                         }
                     }
                 }
@@ -760,18 +741,12 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
                     for (int j = 0; j < NR; ++j)
-#if defined(R50_ABLATE_MFMA)    // diagnostic: one MFMA per fragment pair column instead of MR*NR (keeps every LDS read live)
-                        { if (m == 0 || j == 0) acc[m][j] = mfma_e<ET>(wf[kk][m], xf[kk][j], acc[m][j]); }
-#else
                         acc[m][j] = mfma_e<ET>(wf[kk][m], xf[kk][j], acc[m][j]);
-#endif
             }
-#if !defined(R50_ABLATE_MFMA)
             if constexpr (NCONS + NLOAD <= 8 && ET != 2) {     // 2 waves per SIMD: 256 registers, room for both halves' fragments
                 __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MR + NR), 0);   // every LDS read of the step ...
                 __builtin_amdgcn_sched_group_barrier(0x008, 2 * MR * NR, 0);     // ... then the MFMAs
             }
-#endif
         };
         auto epilogue = [&]() {
 #pragma unroll
@@ -803,7 +778,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
                     if (has_res) {
                         u32x4 r;
                         if constexpr (PREFETCH_RES) r = res_reg[t][j];
-                        else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, 0, R50_RES_AUX);
+                        else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, voff, 0, 0);
                         lo[0] += unpack_lo_e<ET>(r[0]); lo[1] += unpack_hi_e<ET>(r[0]);
                         lo[2] += unpack_lo_e<ET>(r[1]); lo[3] += unpack_hi_e<ET>(r[1]);
                         hi[0] += unpack_lo_e<ET>(r[2]); hi[1] += unpack_hi_e<ET>(r[2]);
@@ -824,11 +799,7 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
                             continue;
                         }
                     }
-#if defined(R50_ABLATE_WS) && (R50_ABLATE_WS & 4)
-                    if (out[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, 0);
-#else
-                    __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, R50_ST_AUX);
-#endif
+                    __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, voff, 0, 0);
                 }
             }
         };
@@ -895,12 +866,6 @@ __global__ __launch_bounds__((CWC * CWP + NLOAD) * 64) void igemm_ws_kernel(cons
 // per K-tile), same cout permutation inside 32-row groups, same epilogue: the bits of tile ids 9 / 12.
 // Operands: 1x1 conv, pad 0, any stride; DUAL: second K source at its own stride (conv3 + downsample of layer3.0 / layer4.0 as one GEMM).
 // ------------------------------------------------------------------------------------------------
-#ifndef G8_LGKM8            // 1 = phase 1 retires only its four b0 reads before the barrier (lgkmcnt(8)); 0 = all twelve (A/B knob)
-#define G8_LGKM8 1
-#endif
-#ifndef G8_PRIO             // s_setprio around every MFMA cluster (guide T5: keeps hipcc from moving MFMAs across the barriers)
-#define G8_PRIO 1
-#endif
 template <int ET, int NR, bool DUAL>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1031,7 +996,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const ConvArgs a) {
             u32x4 rres[2];
             if (has_res) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) rres[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, R50_RES_AUX);
+                for (int t = 0; t < 2; ++t) rres[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff + j * y_rowstep + 64 * t, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -1048,19 +1013,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) out[e] = relu_bf16x2(out[e]);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, y_voff + j * y_rowstep + 64 * t, 0, R50_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(out, rsrc_y, y_voff + j * y_rowstep + 64 * t, 0, 0);
             }
         }
     };
 #define G8_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
 #define G8_LGKM(n) { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#if G8_PRIO
-#define G8_PRIO_UP() __builtin_amdgcn_s_setprio(1)
+#define G8_PRIO_UP() __builtin_amdgcn_s_setprio(1)     // s_setprio around every MFMA cluster (guide T5: keeps hipcc from moving MFMAs across the barriers)
 #define G8_PRIO_DN() __builtin_amdgcn_s_setprio(0)
-#else
-#define G8_PRIO_UP()
-#define G8_PRIO_DN()
-#endif
 
     if (total > 0) {
         bias_fetch(c_tile);
@@ -1092,11 +1052,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const ConvArgs a) {
             for (int kk = 0; kk < 2; ++kk) xf[j][kk] = *reinterpret_cast<const bf16x8*>(kb + x_fr[kk] + j * 2048);
         __builtin_amdgcn_sched_barrier(0);
         stage(integral_constant<int, 3>{});
-#if G8_LGKM8
-        G8_LGKM(8)
-#else
-        G8_LGKM(0)
-#endif
+        G8_LGKM(8)                             // phase 1 retires only its four b0 reads before the barrier
         G8_BARRIER();
         G8_LGKM(0)
         G8_PRIO_UP();
@@ -1245,11 +1201,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
             char* dst = smem + W_BYTES + buf * X_BYTES + lw * 1024;
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) {
-#if defined(C64_ABL) && C64_ABL == 2
-                const unsigned voff = kOobOffset | ((valid >> i) & (base + rel[i]) & 0u);
-#else
                 const unsigned voff = ((valid >> i) & 1u) ? base + rel[i] : kOobOffset;
-#endif
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void*)(dst + i * 4096), 16, voff, 0, 0, 0);
             }
         };
@@ -1322,11 +1274,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
                 }
-#if !(defined(C64_ABL) && C64_ABL == 3)
                 __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_y, (pix0 + 16 * j) * 128u + cout_lane * 2, 0, 0);
-#else
-                if (o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_y, (pix0 + 16 * j) * 128u + cout_lane * 2, 0, 0);
-#endif
             }
         }
     }
@@ -1359,19 +1307,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
 // staggered SIMD partners, 256 couts per tile, three taps per step, the 32x32x16 MFMA with four consumer waves -- all bit-identical except the last,
 // all slower or equal (profiles/r03_xres_variants.txt, r02_ablations_conv3x3_xres.txt); round 4 removed them (git history has them).
 // ------------------------------------------------------------------------------------------------
-// Diagnostic ablations (scripts/build_variant.sh -DXRES_ABL=mask; timing only, results are wrong):
-// 1 = pixel-fragment addresses without the per-tap arithmetic, 4 = no stores, 8 = no MFMAs (reads stay live), 16 = no pixel-fragment
-// reads, 32 = every LDS-DMA zero-fills (issued, no L2 traffic), 64 = the loaders issue no DMA at all (barriers only), 128 = no per-step barrier,
-// 256 = no weight DMAs (input DMAs stay), 512 = no input DMAs (weight DMAs stay)
-#ifndef XRES_ABL
-#define XRES_ABL 0
-#endif
-#ifndef XRES_STATIC_LOADER    // 1 = the unrolled static loader schedule, 0 = the dynamic loader loop (A/B: scripts/build_variant.sh -DXRES_STATIC_LOADER=0)
-#define XRES_STATIC_LOADER 1
-#endif
-#ifndef XRES_PD           // pixel fragments read ahead of their MFMAs
-#define XRES_PD 3
-#endif
 template <int ET, int NI, int TR, int IW, int IH>
 __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1437,7 +1372,6 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                                        : ((rho & ~31) | (rho & 3) | (((rho >> 4) & 1) << 2) | (((rho >> 2) & 3) << 3));
                 const int wkey = RB == 3 ? ((rho >> 1) & 7) : (rho & 7);
                 w_voff[i] = (unsigned)((c0 + cl) * a.Ktot + tt * a.Cin + (slot ^ wkey) * 8) * 2u;
-                if (XRES_ABL & 32) w_voff[i] = kOobOffset;
             }
         };
         auto decode_x = [&](int tile) {           // source offsets of the padded positions of `tile` (out of range = zero border)
@@ -1462,14 +1396,13 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                 // (row blocks: PW = 0 mod 8, so the key of a position is its column's, cc & 7, whatever block and kernel row it is read for)
                 const int key = RB == 3 ? ((cc >> 1) & 7) : RB ? (cc & 7) : ((panel * (TR * IW) + rr * IW + cc) & 7);
                 x_voff[i] = ok ? (unsigned)(((n * IH + y) * IW + x) * a.Cin + (slot ^ key) * 8) * 2u : kOobOffset;
-                if (XRES_ABL & 32) x_voff[i] = kOobOffset;
             }
         };
-        if constexpr (RB == 1 && NST == 3 && XRES_STATIC_LOADER) {
+        {
             // ---- STATIC loader schedule (round 3): the nine iterations of a chunk are unrolled, every iteration issues its weight stage (stage
             // g + 2) and ONE pass of the next chunk's input (two at iteration 0 when the buffer has nine passes) with compile-time pass indices,
-            // and waits with one scalar compare.  The dynamic loop below spends ~85 scalar instructions and ~20 branches per iteration on the same
-            // decisions; beside two consumer waves per SIMD that is time in which its DMAs are not being issued.
+            // and waits with one scalar compare.  (The dynamic loop it replaced spent ~85 scalar instructions and ~20 branches per iteration on the
+            // same decisions; beside two consumer waves per SIMD that is time in which its DMAs are not being issued.  Removed in round 4.)
             // Hazards as the dynamic loop: a pass issued at iteration i (behind barrier i - 1, i.e. after every step of the chunk before this one)
             // is confirmed by the wait of iteration i + 1 and read from the next chunk's step 0 = iteration 9 on; last pass at iteration 7.
             int w_tile = first, w_c = 0, w_s = 0, w_buf = 0;
@@ -1497,6 +1430,7 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
             w_stage();                                                // total >= 9
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPASS) : "memory");          // the first chunk's input and stage 0 landed
             __builtin_amdgcn_s_barrier();
+            R50_STAMP_DECL
             int t_cur = first, c_cur = 0;
             for (int g = 0; g < total; g += 9) {
                 int t_nxt = t_cur, c_nxt = c_cur + 1;
@@ -1518,98 +1452,16 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                         }
                     }
                     const int nx = has_nxt ? (i == 0 ? 1 + EXTRA : (i < 8 ? 1 : 0)) : 0;
+                    R50_MARK(0)                           // DMA issue
                     if (w_ok && nx == 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPASS + 1) : "memory"); }
                     else wait_vmcnt((w_ok ? WPASS : 0) + nx);        // everything issued before this iteration has landed
+                    R50_MARK(1)                           // wait landed
                     __builtin_amdgcn_s_barrier();
+                    R50_MARK(2)                           // barrier
                 }
                 t_cur = t_nxt; c_cur = c_nxt;
             }
-        } else {
-        // stream position of the NEXT step to issue, and of the input chunk that is fetched beside it (one chunk ahead)
-        int i_tile = first, i_c = 0, i_s = 0, i_buf = 0;
-        int x_tile = first, x_c = 0, x_par = 0;                       // chunk being fetched: tile, chunk, buffer
-        auto x_issue = [&](int p0, int p1) {                         // passes [p0, p1) of chunk (x_tile, x_c) into buffer x_par
-            const int xofs = __builtin_amdgcn_readfirstlane(x_c * 128);
-#pragma unroll
-            for (int i = 0; i < XPASS; ++i)
-                if (i >= p0 && i < p1)
-                    if (!(XRES_ABL & (64 | 512))) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LDS_AS void*)(smem + x_par * XBUF + i * 4096 + lw * 1024), 16, x_voff[i], xofs, 0, 0);
-        };
-        // X passes issued beside tap s of a chunk: taps 2..8 carry two passes each (the buffer being refilled was read until tap 8 of the
-        // PREVIOUS chunk, and this loader runs at most D = 2 steps ahead of the consumers)
-        // (TPS = 3: the three steps of a chunk; the loader is one step ahead, so step 0 of a chunk may still overlap the previous chunk's
-        // last step: passes go beside steps 1 and 2)
-        // (SCHED 1: the consumers pass a step's barrier in the MIDDLE of that step and go on reading its input fragments, so the refill
-        // of the other buffer starts one step later)
-        constexpr int XS0 = D + ((SCHED || RB == 2) ? 1 : 0), XPS = (XPASS + (SPC - XS0) - 1) / (SPC - XS0);     // first step that carries passes, passes per step
-        auto xp_lo = [&](int s) { return s < XS0 ? XPASS : (XPS * (s - XS0) < XPASS ? XPS * (s - XS0) : XPASS); };
-        auto xp_hi = [&](int s) { return s < XS0 ? XPASS : (XPS * (s - XS0 + 1) < XPASS ? XPS * (s - XS0 + 1) : XPASS); };
-        static_assert(XPS * (SPC - XS0) >= XPASS, "the chunk's steps carry all input passes");
-        auto ops_of = [&](int g) -> int {         // LDS-DMA instructions of stream step g (per loader wave); 0 past the end
-            if (g >= total) return 0;
-            const int s = g % SPC;
-            const bool has_next_chunk = (g / SPC) + 1 < my_tiles * cch;
-            return WPASS + (has_next_chunk ? xp_hi(s) - xp_lo(s) : 0);
-        };
-        decode_w(i_tile);
-        decode_x(x_tile);
-        x_issue(0, XPASS);                        // the first chunk's input, whole
-        // advance the fetched chunk to (first tile, chunk 1) or the next tile's chunk 0
-        auto x_advance = [&]() {
-            x_par ^= 1;
-            if (++x_c == cch) { x_c = 0; x_tile += grid; decode_x(x_tile); }
-        };
-        x_advance();
-        auto stage_issue = [&](int g) {
-            const int wofs = __builtin_amdgcn_readfirstlane((i_s * TPS * a.Cin + i_c * 64) * 2);
-            char* sbase = smem + WRING + i_buf * WSTAGE + lw * 1024;
-#pragma unroll
-            for (int i = 0; i < WPASS; ++i)
-                if (!(XRES_ABL & (64 | 256))) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LDS_AS void*)(sbase + i * 4096), 16, w_voff[i], wofs, 0, 0);
-            const bool has_next_chunk = (g / SPC) + 1 < my_tiles * cch;
-            if (has_next_chunk && i_s >= XS0) x_issue(xp_lo(i_s), xp_hi(i_s));
-            i_buf = (i_buf == NSTAGE - 1) ? 0 : i_buf + 1;
-            if (++i_s == SPC) {
-                i_s = 0;
-                if (has_next_chunk) x_advance();
-                if (++i_c == cch) {
-                    i_c = 0;
-                    i_tile += grid;
-                    if (i_tile < n_tiles) decode_w(i_tile);
-                }
-            }
-        };
-        static_assert((D - 1) * (WPASS + XPS) <= 63 && D * WPASS <= 63, "vmcnt is 6 bits");
-        // all but the n youngest vector-memory operations of this wave are complete; n = the operations of the D - 1 steps after the one
-        // that must have landed: (D - 1) * WPASS + 0 .. (D - 1) * XPS input passes (or fewer steps at the end of the stream)
-        auto wait_younger = [&](int n) {
-            bool done = false;
-#pragma unroll
-            for (int e = 0; e <= (D - 1) * (WPASS + XPS); ++e)
-                if (!done && n == e) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(e) : "memory"); done = true; }
-            if (!done) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        };
-        auto younger_of = [&](int g) {            // operations of steps g + 2 .. g + D (issued after step g + 1's)
-            int n = 0;
-#pragma unroll
-            for (int i = 2; i <= D; ++i) n += ops_of(g + i);
-            return n;
-        };
-#pragma unroll
-        for (int g0 = 0; g0 < D; ++g0)
-            if (g0 < total) stage_issue(g0);
-        wait_younger(younger_of(-1));             // step 0 (and the first chunk's input, issued before it) landed
-        __builtin_amdgcn_s_barrier();
-        R50_STAMP_DECL
-        for (int g = 0; g < total; ++g) {
-            if (g + D < total) stage_issue(g + D);
-            R50_MARK(0)                           // DMA issue
-            wait_younger(younger_of(g));          // step g+1 landed (steps issued so far: .. g+D)
-            R50_MARK(1)                           // wait landed
-            if (!(XRES_ABL & 128)) __builtin_amdgcn_s_barrier();
-            R50_MARK(2)                           // barrier
-        }
-        R50_STAMP_FLUSH(12)
+            R50_STAMP_FLUSH(12)
         }
     } else {
         // =============================== consumer waves =============================================
@@ -1634,8 +1486,9 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
         int c_buf = 0, x_par = 0;
         // RB: see the kernel's head.  Ring slot of tap s is s % 3 (nine steps per chunk, three stages), so with the nine taps unrolled every LDS
         // address of the K loop is a lane constant + an immediate.
+        R50_STAMP_DECL
         auto run_steps_rb = [&]() {
-            constexpr int NRW = 7, PD = XRES_PD;
+            constexpr int NRW = 7, PD = 3;            // PD: pixel fragments read ahead of their MFMAs
             constexpr bool W2 = (MR <= 2);
             const char* const xl = smem + BSTEP * 2048 * wave_p;       // this pixel half's first block
             int vb[3][2];                                               // [tap column][K half]: position fr + kw, chunk (fq + 4 kk) ^ key
@@ -1648,6 +1501,7 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
             int x_par = 0;
             for (int tile = first; tile < n_tiles; tile += grid) {
                 const int c0 = (tile % nct) * BC;
+                R50_MARK(0)                                             // tile begin
 #pragma unroll
                 for (int t = 0; t < MR / 2; ++t) {
                     const f32x4 b_lo = *reinterpret_cast<const f32x4*>(a.bias + c0 + cout_lane + 32 * t);
@@ -1667,8 +1521,7 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                         const char* const w1 = wl1 + (NSTAGE == 3 ? tap % 3 : c_buf) * WSTAGE;
                         if constexpr (NSTAGE != 3) c_buf = (c_buf == NSTAGE - 1) ? 0 : c_buf + 1;
                         auto xread = [&](int t) {
-                            if constexpr (XRES_ABL & 16) return __builtin_bit_cast(bf16x8, (u32x4){(unsigned)(size_t)x0, 1u, 2u, (unsigned)t});
-                            else return *reinterpret_cast<const bf16x8*>((t >= NRW ? x1 : x0) + (t % NRW) * 2048);
+                            return *reinterpret_cast<const bf16x8*>((t >= NRW ? x1 : x0) + (t % NRW) * 2048);
                         };
                         bf16x8 x[2 * NRW], wf[MR], wg[W2 ? MR : 1];
 #pragma unroll
@@ -1689,8 +1542,7 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                             }
 #pragma unroll
                             for (int m = 0; m < MR; ++m) {
-                                if constexpr (XRES_ABL & 8) { asm volatile("" ::"v"((W2 && t >= NRW) ? wg[m] : wf[m]), "v"(x[t])); }
-                                else acc[m][t % NRW] = mfma_e<ET>((W2 && t >= NRW) ? wg[m] : wf[m], x[t], acc[m][t % NRW]);
+                                acc[m][t % NRW] = mfma_e<ET>((W2 && t >= NRW) ? wg[m] : wf[m], x[t], acc[m][t % NRW]);
                             }
                             if (t + PD < 2 * NRW) x[t + PD] = xread(t + PD);
                         }
@@ -1702,7 +1554,9 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                             if (t + PD < 2 * NRW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);              // the barrier stays behind the step's last fragment read
-                        if (!(XRES_ABL & 128)) __builtin_amdgcn_s_barrier();
+                        R50_MARK(1)                                     // fragment reads + MFMAs
+                        __builtin_amdgcn_s_barrier();
+                        R50_MARK(2)                                     // barrier
                     }
                     x_par ^= 1;
                 }
@@ -1726,13 +1580,23 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
                             for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
                         }
                         const unsigned voff = ok ? (pix * (unsigned)a.Cout + (unsigned)(c0 + cout_lane + 32 * t)) * 2u : kOobOffset;
-                        if (!(XRES_ABL & 4) || o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff, 0, 0);
                     }
                 }
+                R50_MARK(3)                                             // epilogue (and the next tile's bias loads land in slot 0)
             }
         };
         __builtin_amdgcn_s_barrier();             // step 0 and the first input chunk landed
+#if defined(R50_STAMP)
+        const unsigned long long clk0 = __builtin_readcyclecounter();
+        st_sum[5] = clk0 - t_entry;               // kernel entry -> first stage landed (prologue)
+        st_prev = clk0;
+#endif
         run_steps_rb();
+#if defined(R50_STAMP)
+        st_sum[6] = __builtin_readcyclecounter() - clk0;      // shader cycles of the loop; slot 7 (100-MHz ticks, from before the first barrier) is set by the flush
+#endif
+        R50_STAMP_FLUSH(12)
     }
 #else
     (void)a;
@@ -2018,22 +1882,7 @@ struct TailArgs {
     int M;
 };
 
-#ifndef TAIL_AUX
-#define TAIL_AUX 0
-#endif
 // finer A/B knobs of the layer1 tail's streams (aux bits: 2 = nt): identity loads, block-output stores, conv2-output loads, next-t1 stores
-#ifndef TAIL_LD_AUX
-#define TAIL_LD_AUX TAIL_AUX
-#endif
-#ifndef TAIL_ST_AUX
-#define TAIL_ST_AUX TAIL_AUX
-#endif
-#ifndef TAIL_X_AUX
-#define TAIL_X_AUX 0
-#endif
-#ifndef TAIL_Y1_AUX
-#define TAIL_Y1_AUX 0
-#endif
 
 template <int ET, int C1, bool DS, int NT>
 __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
@@ -2098,13 +1947,13 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
     auto first_loads = [&](int tile, u32x4 (&xf)[2], u32x4 (&rs)[NRS]) {
         const unsigned pix = (unsigned)(tile * 16 + fr);           // past M: the descriptor returns zeros
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) xf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_y2, pix * 128u + kk * 64 + fq * 16, 0, TAIL_X_AUX);
+        for (int kk = 0; kk < 2; ++kk) xf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_y2, pix * 128u + kk * 64 + fq * 16, 0, 0);
         if constexpr (DS) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) rs[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix * 128u + kk * 64 + fq * 16, 0, 0);
         } else {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix * 512u + t * 64 + fq * 16, 0, TAIL_LD_AUX);
+            for (int t = 0; t < 8; ++t) rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix * 512u + t * 64 + fq * 16, 0, 0);
         }
     };
     // TAIL_PF register sets, used round robin (loop unrolled by TAIL_PF so they are indexed statically): a set's loads for
@@ -2155,15 +2004,15 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
             outp[t] = o;
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, pix * 512u + t * 64 + fq * 16, 0, TAIL_ST_AUX);
-            if constexpr (!DS) rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix_n * 512u + t * 64 + fq * 16, 0, TAIL_LD_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, pix * 512u + t * 64 + fq * 16, 0, 0);
+            if constexpr (!DS) rs[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix_n * 512u + t * 64 + fq * 16, 0, 0);
         }
         if constexpr (DS) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) rs[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, pix_n * 128u + kk * 64 + fq * 16, 0, 0);
         }
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) xf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_y2, pix_n * 128u + kk * 64 + fq * 16, 0, TAIL_X_AUX);
+        for (int kk = 0; kk < 2; ++kk) xf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_y2, pix_n * 128u + kk * 64 + fq * 16, 0, 0);
         // ---- next conv1: (C1 x 256) x (256 x 16 pixels), K blocks straight from outp
         f32x4 acc2[M2];
 #pragma unroll
@@ -2187,7 +2036,7 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const TailArgs a) {
                               pack2_e<ET>(hi[2], hi[3])};
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, pix * (C1 * 2u) + t2 * 64 + fq * 16, 0, TAIL_Y1_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, pix * (C1 * 2u) + t2 * 64 + fq * 16, 0, 0);
         }
         };
     u32x4 xfA[2], rsA[NRS], xfB[2], rsB[NRS];
@@ -2448,24 +2297,11 @@ __global__ void tail3_pack_kernel(const __bf16* __restrict__ w3, const __bf16* _
 // and of the two igemm launches.
 // LDS: T2 [4 slots][ROWS] + out_c 2 x [2 slots][ROWS] rows of 128 B + b1 + b3 = 119,808 B at ROWS = 112.
 // ------------------------------------------------------------------------------------------------
-#ifndef T3P_ABL           // diagnostic ablations (timing only): 1 = no identity loads, 2 = no HBM stores, 4 = no MFMAs, 8 = no E work, 16 = no pixel-fragment LDS reads, 32 = no weight loads
-#define T3P_ABL 0
-#endif
-#ifndef T3P_XPRE          // cross-step prefetch of the first pixel fragments of the next step (1 = group A, 2 = group B): measured neutral
-#define T3P_XPRE 0
-#endif
-#ifndef T3P_COPY          // who writes the block output: 0 = group A straight from its E-phase registers (64-B pieces), 1 = group B copies out_c out of LDS (full rows)
-#define T3P_COPY 1        // stamps: 102 k cycles per wave and launch with the copy-out against 128 k with 64-B pieces from group A's registers
-#endif
-#ifndef T3P_PRIO          // wave priority: 1 = group B at s_setprio 1, 2 = group A at s_setprio 1, 4 = group A at s_setprio 2 during its E phase
-#define T3P_PRIO 0
-#endif
-#ifndef T3P_PDA           // LDS prefetch depth (pixel fragments) of the A / B weight steps
-#define T3P_PDA 6
-#endif
-#ifndef T3P_PDB
-#define T3P_PDB 6
-#endif
+constexpr int T3P_XPRE = 0;   // cross-step prefetch of the first pixel fragments of the next step (1 = group A, 2 = group B): measured neutral, off
+// The block output is written by group B, which copies out_c out of LDS in full rows (stamps: 102 k cycles per wave and launch against 128 k
+// with 64-B pieces straight from group A's E-phase registers).
+constexpr int T3P_PDA = 6;    // LDS prefetch depth (pixel fragments) of the A / B weight steps
+constexpr int T3P_PDB = 6;
 // NOB (layer3.5, whose next conv1 is layer4.0's 1024 -> 512 and does not fit the chain): group B only copies out_c out -- conv3 + identity + ReLU of
 // the stage's last block through the same pipeline, no second GEMM, no y1n (the weight stream's W1 slices are never read).
 template <int ET, int ROWS, bool NOB = false>
@@ -2502,8 +2338,7 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
         const int sofs = __builtin_amdgcn_readfirstlane((((((g >> 2) & 7) << 3) + (g & 3) + gofs)) << 14);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            if constexpr (T3P_ABL & 32) wf[2 * m + kk] = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)sofs, 1u, 2u, 3u});
-            else wf[2 * m + kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wp, wp_voff + (2 * m + kk) * 1024, sofs, 0));
+            wf[2 * m + kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wp, wp_voff + (2 * m + kk) * 1024, sofs, 0));
         }
     };
     // one weight step: acc[m][j] += W[32w + 16m ..][64 K] . X[64 K][16 j ..]; 14 slots t = 7 kk + j of one pixel fragment and two MFMAs, the
@@ -2517,16 +2352,14 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
         constexpr bool HAVE = decltype(have_c)::value, NXT = decltype(nxt_c)::value;
         bf16x8 x[NS];
         auto xread = [&](const char* b, int t) {
-            if constexpr (T3P_ABL & 16) return __builtin_bit_cast(bf16x8, (u32x4){(unsigned)(size_t)b, (unsigned)t, 2u, 3u});
-            else return *reinterpret_cast<const bf16x8*>(b + x_frag + (t % NR) * 2048 + (t >= NR ? (fphys0 ^ 64) : fphys0));
+            return *reinterpret_cast<const bf16x8*>(b + x_frag + (t % NR) * 2048 + (t >= NR ? (fphys0 ^ 64) : fphys0));
         };
 #pragma unroll
         for (int t = 0; t < PD; ++t) x[t] = HAVE ? xq[t] : xread(xb, t);
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             const int j = t % NR, kk = t / NR;
-            if constexpr (T3P_ABL & 4) { asm volatile("" ::"v"(wf[kk]), "v"(wf[2 + kk]), "v"(x[t])); }
-            else {
+            {
                 acc0[j] = mfma_e<ET>(wf[kk], x[t], acc0[j]);
                 acc1[j] = mfma_e<ET>(wf[2 + kk], x[t], acc1[j]);
             }
@@ -2591,14 +2424,13 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
         tile_rows(first + grid, rvn);
         issue_t2(first);
 #pragma unroll
-        for (int j = 0; j < NR; ++j) r0[j] = (T3P_ABL & 1) ? (u32x4){0u, 0u, 0u, 0u} : __builtin_amdgcn_raw_buffer_load_b128(rs_res, rv[j], 0, 0);
+        for (int j = 0; j < NR; ++j) r0[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, rv[j], 0, 0);
 #pragma unroll
-        for (int j = 0; j < NR; ++j) r1[j] = (T3P_ABL & 1) ? (u32x4){0u, 0u, 0u, 0u} : __builtin_amdgcn_raw_buffer_load_b128(rs_res, rv[j], 256, 0);
+        for (int j = 0; j < NR; ++j) r1[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, rv[j], 256, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { w_load_half(q, 0, wq[q], 0); w_load_half(q, 0, wq[q], 1); }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // own t2 pieces landed, own bias words written
         __builtin_amdgcn_s_barrier();             // P
-        if (T3P_PRIO & 2) __builtin_amdgcn_s_setprio(1);
         int g = 0;
         R50_STAMP_DECL
         // one chunk of group A: c = 2 c2 + PAR; `r` is the register set of its parity
@@ -2625,35 +2457,26 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
 #endif
             R50_MARK(0)                           // A: 4 weight steps
             __builtin_amdgcn_sched_barrier(0);
-            // ---- E: + identity, ReLU, 16 bit -> out_c[c & 1] and (T3P_COPY = 0) the block output; the identity of chunk c + 2 (of the next
+            // ---- E: + identity, ReLU, 16 bit -> out_c[c & 1]; the identity of chunk c + 2 (of the next
             // tile after chunks 6 and 7) is requested into the registers this chunk has just consumed
-            if (T3P_PRIO & 4) __builtin_amdgcn_s_setprio(2);
             const bool nxt = (c2 == NCH / 2 - 1);
             const int cofs_n = __builtin_amdgcn_readfirstlane(((c + 2) & (NCH - 1)) * 256);
-            const int cofs_c = __builtin_amdgcn_readfirstlane(c * 256);
             char* ob = smem + OUTC + PAR * 2 * SLOT + c_frag;
             u32x4 o[NR];
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
-                if (!(T3P_ABL & 8)) {
-                    f32x4 lo = accA[0][j], hi = accA[1][j];
-                    lo[0] += unpack_lo_e<ET>(r[j][0]); lo[1] += unpack_hi_e<ET>(r[j][0]);
-                    lo[2] += unpack_lo_e<ET>(r[j][1]); lo[3] += unpack_hi_e<ET>(r[j][1]);
-                    hi[0] += unpack_lo_e<ET>(r[j][2]); hi[1] += unpack_hi_e<ET>(r[j][2]);
-                    hi[2] += unpack_lo_e<ET>(r[j][3]); hi[3] += unpack_hi_e<ET>(r[j][3]);
-                    o[j] = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
+                f32x4 lo = accA[0][j], hi = accA[1][j];
+                lo[0] += unpack_lo_e<ET>(r[j][0]); lo[1] += unpack_hi_e<ET>(r[j][0]);
+                lo[2] += unpack_lo_e<ET>(r[j][1]); lo[3] += unpack_hi_e<ET>(r[j][1]);
+                hi[0] += unpack_lo_e<ET>(r[j][2]); hi[1] += unpack_hi_e<ET>(r[j][2]);
+                hi[2] += unpack_lo_e<ET>(r[j][3]); hi[3] += unpack_hi_e<ET>(r[j][3]);
+                o[j] = (u32x4){pack2_e<ET>(lo[0], lo[1]), pack2_e<ET>(lo[2], lo[3]), pack2_e<ET>(hi[0], hi[1]), pack2_e<ET>(hi[2], hi[3])};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[j][e] = relu_bf16x2(o[j][e]);
-                    if (ROWS >= 16 * j + 16 || fr < ROWS - 16 * j) *reinterpret_cast<u32x4*>(ob + j * 2048) = o[j];
-                } else o[j] = r[j];
-                if (!(T3P_ABL & 1)) r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, nxt ? rvn[j] : rv[j], cofs_n, 0);
-            }
-            if (T3P_COPY == 0 && !(T3P_ABL & 2)) {
-#pragma unroll
-                for (int j = 0; j < NR; ++j) __builtin_amdgcn_raw_buffer_store_b128(o[j], rs_out, rv[j], cofs_c, 0);
+                for (int e = 0; e < 4; ++e) o[j][e] = relu_bf16x2(o[j][e]);
+                if (ROWS >= 16 * j + 16 || fr < ROWS - 16 * j) *reinterpret_cast<u32x4*>(ob + j * 2048) = o[j];
+                r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, nxt ? rvn[j] : rv[j], cofs_n, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // out_c written before anybody reads it
-            if (T3P_PRIO & 4) __builtin_amdgcn_s_setprio((T3P_PRIO & 2) ? 1 : 0);
             R50_MARK(1)                           // E
             __builtin_amdgcn_s_barrier();
             R50_MARK(2)                           // chunk barrier
@@ -2703,7 +2526,7 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
                     const unsigned voff = (16 * j + fr < limit) ? (unsigned)((p0 + 16 * j + fr) * C1N + 128 * t + 32 * w + 8 * fq) * 2u : kOobOffset;
-                    if (!(T3P_ABL & 2) || o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, voff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, voff, 0, 0);
                 }
         };
         if constexpr (!NOB) {
@@ -2712,7 +2535,6 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();             // P
-        if (T3P_PRIO & 1) __builtin_amdgcn_s_setprio(1);
         int g = 0;
         int prev = -1;
         R50_STAMP_DECL
@@ -2749,15 +2571,15 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
 #endif
                 R50_MARK(2)                       // B: 4 weight steps
                 __builtin_amdgcn_sched_barrier(0);
-                // ---- (T3P_COPY = 1) copy-out of out_c[c & 1]: full 128-B row pieces, 16 B per lane
-                if (T3P_COPY) {
+                // ---- copy-out of out_c[c & 1]: full 128-B row pieces, 16 B per lane
+                {
                     const int cofs = __builtin_amdgcn_readfirstlane(c * 256);
                     u32x4 v[OC_PASSES];
 #pragma unroll
                     for (int i = 0; i < OC_PASSES; ++i) v[i] = *reinterpret_cast<const u32x4*>(xb + i * 4096 + lt * 16);
 #pragma unroll
                     for (int i = 0; i < OC_PASSES; ++i)
-                        if (!(T3P_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, rvo[i], cofs, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, rvo[i], cofs, 0);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of out_c[c & 1] are complete
                 R50_MARK(3)                       // copy-out
@@ -2818,18 +2640,8 @@ __global__ void catchain_pack_kernel(const __bf16* __restrict__ wcat, const __bf
     reinterpret_cast<u32x4*>(wp)[idx] = *reinterpret_cast<const u32x4*>(src);
 }
 
-#ifndef CC_ABL            // diagnostic ablations (timing only): 2 = no HBM stores, 4 = no MFMAs
-#define CC_ABL 0
-#endif
-#ifndef CC_PRIO           // 1 = group B at s_setprio 1 (its two steps per chunk then finish early and its copy-out / operand issue run beside group A's six)
-#define CC_PRIO 0
-#endif
-#ifndef CC_WDA            // group A's weight prefetch distance in steps: 2 or 4
-#define CC_WDA 4
-#endif
-#ifndef CC_PD             // LDS prefetch depth (pixel fragments) of a weight step
-#define CC_PD 6
-#endif
+constexpr int CC_WDA = 4;     // group A's weight prefetch distance in steps (2 or 4)
+constexpr int CC_PD = 6;      // LDS prefetch depth (pixel fragments) of a weight step
 template <int ET, int OW>
 __global__ __launch_bounds__(512) void bneck_catchain_kernel(const CatChainArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2874,8 +2686,7 @@ __global__ __launch_bounds__(512) void bneck_catchain_kernel(const CatChainArgs 
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             const int j = t % NR, kk = t / NR;
-            if constexpr (CC_ABL & 4) { asm volatile("" ::"v"(wf[kk]), "v"(wf[2 + kk]), "v"(x[t])); }
-            else {
+            {
                 acc0[j] = mfma_e<ET>(wf[kk], x[t], acc0[j]);
                 acc1[j] = mfma_e<ET>(wf[2 + kk], x[t], acc1[j]);
             }
@@ -3038,7 +2849,7 @@ __global__ __launch_bounds__(512) void bneck_catchain_kernel(const CatChainArgs 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = relu_bf16x2(o[e]);
                 const unsigned voff = (16 * j + fr < limit) ? (unsigned)((p0 + 16 * j + fr) * C1N + 32 * w + 8 * fq) * 2u : kOobOffset;
-                if (!(CC_ABL & 2) || o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, voff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_y1, voff, 0, 0);
             }
         };
         auto init_accb = [&]() {                  // accB[e]: channels 32w + 8fq + 4e ..
@@ -3053,7 +2864,6 @@ __global__ __launch_bounds__(512) void bneck_catchain_kernel(const CatChainArgs 
         w_load_half(sofs_of(0, 7), wB, 0); w_load_half(sofs_of(0, 7), wB, 1);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // own operand pieces landed, own bias words written
         __builtin_amdgcn_s_barrier();             // P
-        if (CC_PRIO & 1) __builtin_amdgcn_s_setprio(1);
         init_accb();
         __builtin_amdgcn_s_barrier();             // first interval: group A is on chunk 0 of its first tile
         unsigned tl = 0;
@@ -3089,7 +2899,7 @@ __global__ __launch_bounds__(512) void bneck_catchain_kernel(const CatChainArgs 
                     for (int i = 0; i < OC_PASSES; ++i) v[i] = *reinterpret_cast<const u32x4*>(xb + i * 4096 + lt * 16);
 #pragma unroll
                     for (int i = 0; i < OC_PASSES; ++i)
-                        if (!(CC_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, rvo[i], cofs, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, rvo[i], cofs, 0);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 R50_MARK(3)                       // copy-out
@@ -3158,20 +2968,7 @@ struct Block2Args {
     int n_tiles;          // 4 N
 };
 
-// Diagnostic ablations (scripts/build_variant.sh -DB2_ABL=mask; timing only, results are wrong): 1 = no MFMAs (reads stay live),
-// 2 = identity DMAs zero-fill and the block output is not stored, 4 = band DMAs zero-fill, 8 = weight-stage DMAs zero-fill,
-// 16 = the loaders issue neither identity DMAs nor the copy-out (no instructions at all)
-#ifndef B2_ABL
-#define B2_ABL 0
-#endif
-#ifndef B2_LOADER_UNROLL      // 1 = the loaders' position loop fully unrolled; 0 = rolled (A/B: scripts/build_variant.sh -DB2_LOADER_UNROLL=0)
-#define B2_LOADER_UNROLL 1
-#endif
-#if B2_LOADER_UNROLL
-#define B2_LOADER_LOOP _Pragma("unroll")
-#else
-#define B2_LOADER_LOOP _Pragma("unroll 1")
-#endif
+#define B2_LOADER_LOOP _Pragma("unroll")      // the loaders' position loop fully unrolled (rolled: 4-20 % slower bodies, profiles/r03_block_loader_unroll_ab.txt)
 template <int ET, int C1N>
 __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -3223,7 +3020,6 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
             const unsigned ch = (unsigned)((slot ^ (rho & 7)) * 8);
             w2v[i] = ((unsigned)cl * 1152u + ch) * 2u;
             w1v[i] = ((unsigned)cl * 512u + ch) * 2u;
-            if (B2_ABL & 8) { w2v[i] = kOobOffset; w1v[i] = kOobOffset; }
             if (C1N) {                                                   // A stage: rows 64 ks + rho' = K-slot ks of cout perm(rho') of the chunk
                 const int rp = rho & 63, ks = rho >> 6;
                 const int cl2 = (rp & ~31) | (rp & 3) | (((rp >> 4) & 1) << 2) | (((rp >> 2) & 3) << 3);
@@ -3231,7 +3027,6 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
             } else {
                 w3v[i] = ((unsigned)cl * 128u + ch) * 2u;
             }
-            if (B2_ABL & 8) w3v[i] = kOobOffset;
         }
         auto decode_band = [&](int tile) {        // source offsets of the padded positions of `tile` (out of range = zero border)
             const int n = tile >> 2, band = tile & 3;
@@ -3242,7 +3037,7 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
                 const int y = band * TR + rr - 1, x = cc - 1;
                 const bool ok = q < PP && tile < a.n_tiles && (unsigned)y < 28u && (unsigned)x < 28u;
                 // chunk key of a position = its column's, cc & 7 (PW = 0 mod 8): the same for every block and kernel row a lane reads it for
-                x_voff[i] = (ok && !(B2_ABL & 4)) ? (unsigned)(((n * 28 + y) * 28 + x) * 128 + (slot ^ (cc & 7)) * 8) * 2u : kOobOffset;
+                x_voff[i] = (ok) ? (unsigned)(((n * 28 + y) * 28 + x) * 128 + (slot ^ (cc & 7)) * 8) * 2u : kOobOffset;
             }
         };
         auto issue_band = [&](int c2) {           // 9 DMAs per wave: chunk c2 of the band decoded last
@@ -3261,7 +3056,7 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int R = 32 * i + srow;
-            rv[i] = (R < NPX && !(B2_ABL & 2)) ? ((unsigned)R * 512u + (unsigned)((slot ^ (R & 7)) * 8)) * 2u : kOobOffset;
+            rv[i] = (R < NPX) ? ((unsigned)R * 512u + (unsigned)((slot ^ (R & 7)) * 8)) * 2u : kOobOffset;
         }
         auto issue_res = [&](unsigned tile_pix0, int c) {       // 7 DMAs per wave
             const int sofs = __builtin_amdgcn_readfirstlane((int)(tile_pix0 * 1024u) + c * 128);
@@ -3336,18 +3131,18 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
                 if (p == PBAND && has_next) { decode_band(tile + grid); issue_band(0); if (C1N) younger = 0; else younger += XPASS; }
                 const bool bpos = C1N && p > NCONV && ((p - NCONV) & 1) == 1;      // B stage of chunk (p - 19) / 2
                 // identity rows of the NEXT chunk (chunk 0: two stages before the first A stage): needed one barrier later
-                if (C1N && p == NCONV - 2 && !(B2_ABL & 16)) { issue_res(tile_pix0, 0); younger += 7; }
-                if (bpos && p + 1 < SPT && !(B2_ABL & 16)) { issue_res(tile_pix0, (p - NCONV + 1) / 2); younger += 7; }
+                if (C1N && p == NCONV - 2) { issue_res(tile_pix0, 0); younger += 7; }
+                if (bpos && p + 1 < SPT) { issue_res(tile_pix0, (p - NCONV + 1) / 2); younger += 7; }
                 const bool st = (p + 2 < SPT) || has_next;
                 if (st) { stage_issue(p + 2 < SPT ? p + 2 : p + 2 - SPT); younger += WPASS; }
                 // What the loaders do per iteration has to stay below what the consumers do per stage (~1,000-1,400 cycles), or every barrier
-                // waits for the loaders (-DB2_ABL=16: without the identity / copy-out instructions the launch takes 123 us instead of 158).
+                // waits for the loaders (an ablation build without the identity / copy-out instructions took 123 us instead of 158).
                 // out_c(c) is complete behind the extra barrier in front of B(c) and stays intact until E(c + 1), i.e. over two iterations:
                 // its copy-out (LDS -> HBM) goes into the SECOND one, the A(c + 1) position, which carries nothing but a weight stage (with
                 // identity DMAs, stage and copy-out all in the B position: 155 us; so: 145 us).  Chunk 7 has no A position behind it: copied
                 // at its own B position.  (Also tried: identity rows and the next band prefetched into loader REGISTERS two iterations
                 // early and written to LDS when the buffer falls free, instead of an LDS-DMA issued at that moment: 155 us, slower.)
-                const bool cpos = C1N && !(B2_ABL & 16) && p > NCONV + 1 && (((p - NCONV) & 1) == 0 || p == SPT - 1);
+                const bool cpos = C1N && p > NCONV + 1 && (((p - NCONV) & 1) == 0 || p == SPT - 1);
                 if (cpos) {                       // the stores are not waited for here, nor at the next iteration (whose wait covers this iteration's DMAs)
                     copy_out(tile_pix0, p == SPT - 1 ? 7 : (p - NCONV) / 2 - 1);
                     younger += 7;
@@ -3396,8 +3191,7 @@ __global__ __launch_bounds__(768) void bneck_block2_kernel(const Block2Args a) {
                 for (int t = 0; t < NS; ++t) {
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        if constexpr (B2_ABL & 1) { asm volatile("" ::"v"(t >= NB ? wg[m] : wf[m]), "v"(x[t])); }
-                        else ac[m][t % NB] = mfma_e<ET>(t >= NB ? wg[m] : wf[m], x[t], ac[m][t % NB]);
+                        ac[m][t % NB] = mfma_e<ET>(t >= NB ? wg[m] : wf[m], x[t], ac[m][t % NB]);
                     }
                     if (t + PD < NS) x[t + PD] = *reinterpret_cast<const bf16x8*>(xaddr(t + PD));
                 }
