@@ -2621,6 +2621,7 @@ struct CatChainArgs {
     int bp;               // real pixels per tile (<= 112)
     int n_tiles;
     unsigned x_bytes;     // N * 4 OW OW * 512
+    int x_sub;            // 1: x is already the compact (N, OW, OW, 256) tensor of the block input's even rows and columns (x_bytes = N OW OW 512)
 #if defined(R50_STAMP)
     unsigned long long* dbg;
 #endif
@@ -2807,7 +2808,7 @@ __global__ __launch_bounds__(512) void bneck_catchain_kernel(const CatChainArgs 
                 const int lchunk = (lt & 7) ^ (prow & 7);
                 const unsigned p = (unsigned)(p0 + prow);
                 const unsigned n = p / HOWO, r = p - n * HOWO, ho = r / OW, wo = r - ho * OW;
-                const unsigned q = (n * WI + 2 * ho) * WI + 2 * wo;
+                const unsigned q = a.x_sub ? p : (n * WI + 2 * ho) * WI + 2 * wo;
                 const bool ok = prow < limit;
                 vt[k] = ok ? (p * CT2 + lchunk * 8) * 2u : kOobOffset;
                 vx[k] = ok ? (q * CX + lchunk * 8) * 2u : kOobOffset;
@@ -3396,6 +3397,8 @@ struct Block1Args {
     __bf16* y1n;          // (M, C1N)
     int N;
     int n_tiles;          // 14 N
+    int out_sub;          // 1: only the block output's even rows and columns are stored, as a compact (N,28,28,256) tensor -- layer1.2, whose
+                          //    output has two readers: layer2.0.conv1 (computed here, from LDS) and layer2.0's stride-2 downsample conv
 };
 
 template <int ET, int C1N, bool DS = false>
@@ -3442,7 +3445,7 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
         const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)a.N * (3136u * (DS ? 128u : 512u)), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_wd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(DS ? a.wd : a.w3), 0, 256u * 64u * 2u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.N * (3136u * 512u), 0x00020000);
-        unsigned w2v[WPASS], w3v[WPASS], w1v[WPASS], x_voff[XPASS], rv[7], rvx[7];
+        unsigned w2v[WPASS], w3v[WPASS], w1v[WPASS], x_voff[XPASS], rv[7], rvx[7], rvs[7];
 #pragma unroll
         for (int i = 0; i < WPASS; ++i) {
             const int rho = i * 32 + srow;                               // LDS row of the stage (< 64)
@@ -3457,6 +3460,10 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
             const int R = 32 * i + srow;
             rv[i] = ((unsigned)R * 256u + (unsigned)((slot ^ (R & 7)) * 8)) * 2u;
             rvx[i] = ((unsigned)R * 64u + (unsigned)((slot ^ (R & 7)) * 8)) * 2u;          // DS: the same rows of the 64-channel block input
+            // out_sub: pixel R = (tile row R / 56, column R % 56) is kept if both are even; the tile's 2 x 28 kept pixels are rows 2 tr, 2 tr + 1
+            // of the compact tensor (its pixel index of the tile's first pixel = tile_pix0 / 4); the others are dropped by the range check
+            const int sr = R / 56, sc = R - 56 * sr;
+            rvs[i] = (a.out_sub && !((sr | sc) & 1)) ? ((unsigned)((sr >> 1) * 28 + (sc >> 1)) * 256u + (unsigned)((slot ^ (R & 7)) * 8)) * 2u : kOobOffset;
         }
         auto decode_band = [&](int tile) {        // source offsets of the padded positions of `tile` (out of range = zero border)
             const int n = tile / 14, tr = tile - n * 14;
@@ -3482,12 +3489,12 @@ __global__ __launch_bounds__(768) void bneck_block1_kernel(const Block1Args a) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (LDS_AS void*)(smem + RESB_OFF + i * 4096 + lw * 1024), 16, DS ? rvx[i] : rv[i], sofs, 0, 0);
         };
         auto copy_out = [&](unsigned tile_pix0, int c) {        // 7 LDS reads + 7 stores per wave: out_c -> block output
-            const int sofs = __builtin_amdgcn_readfirstlane((int)(tile_pix0 * 512u) + c * 128);
+            const int sofs = __builtin_amdgcn_readfirstlane((int)((a.out_sub ? tile_pix0 >> 2 : tile_pix0) * 512u) + c * 128);
             u32x4 v[7];
 #pragma unroll
             for (int i = 0; i < 7; ++i) v[i] = *reinterpret_cast<const u32x4*>(smem + OUTC_OFF + i * 4096 + lt * 16);
 #pragma unroll
-            for (int i = 0; i < 7; ++i) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, rv[i], sofs, 0);
+            for (int i = 0; i < 7; ++i) __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_out, a.out_sub ? rvs[i] : rv[i], sofs, 0);
         };
         int ring = 0;                             // ring slot of the next stage to issue
         auto stage_issue = [&](int p) {           // stage p (0 .. SPT-1) of a tile; 2 DMAs per wave

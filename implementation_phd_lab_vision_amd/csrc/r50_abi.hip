@@ -71,6 +71,8 @@ struct r50_handle {
     __bf16* catchain_wp = nullptr;      // layer2.0: [W3 | Wd] and layer2.1.conv1 in bneck_catchain_kernel's fragment-ordered stream
     int fuse_tail3_last = 1;            // layer3.5: conv3 + identity + ReLU through the pipelined tail kernel without a second GEMM
     int fuse_cat_chain = 1;             // layer2.0: conv3 + downsample + ReLU chained with layer2.1.conv1 in one launch (bneck_catchain_kernel)
+    int sub_out = 1;                    // layer1.2 stores only the even rows / columns of its output (its readers: the fused layer2.0.conv1 and the stride-2 downsample
+                                        // conv inside bneck_catchain_kernel); needs fuse_block1 >= 2 and the chained layer2.0 tail, else the full tensor is written
     __bf16* tail3_wp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per layer3 block b: [W3(b) | W1(b+1)] in the kernel's fragment order
     int fuse_block1 = 3;                // 1: layer1.1, 2 (default since round 3: with the loaders' position loop unrolled the c1 = 128 form takes 248 us against
                                         // 276 for conv2 + fused tail): also layer1.2 -- the bottleneck body in one launch (bneck_block1_kernel)
@@ -850,8 +852,9 @@ hipError_t pack_catchain_weights(const void* wcat, const void* w1, void* wp, hip
     hipLaunchKernelGGL(catchain_pack_kernel, dim3(32768 / 256), dim3(256), 0, s, (const __bf16*)wcat, (const __bf16*)w1, (__bf16*)wp);
     return hipGetLastError();
 }
+// x_sub: x is the compact (N, ow, ow, 256) tensor of the block input's even rows and columns (what bneck_block1_kernel writes with out_sub)
 hipError_t launch_bneck_catchain(const void* t2, const void* x, int n, int ow, const void* wp, const float* bcat, void* out,
-                                 const float* b1, void* y1n, hipStream_t s, int et = 0) {
+                                 const float* b1, void* y1n, hipStream_t s, int et = 0, bool x_sub = false) {
     if (!t2 || !x || !wp || !bcat || !out || !b1 || !y1n || n <= 0 || ow != 28) return hipErrorInvalidValue;
     const long long m = (long long)n * ow * ow;
     if (m * 1024 >= (1ll << 31) || (long long)n * 4 * ow * ow * 512 >= (1ll << 31)) return hipErrorInvalidValue;
@@ -863,7 +866,7 @@ hipError_t launch_bneck_catchain(const void* t2, const void* x, int n, int ow, c
     }
     CatChainArgs a;
     a.t2 = (const __bf16*)t2; a.x = (const __bf16*)x; a.wp = (const __bf16*)wp; a.b3 = bcat; a.out = (__bf16*)out; a.b1 = b1; a.y1n = (__bf16*)y1n;
-    a.M = (int)m; a.x_bytes = (unsigned)((long long)n * 4 * ow * ow * 512);
+    a.M = (int)m; a.x_bytes = (unsigned)((long long)n * (x_sub ? 1 : 4) * ow * ow * 512); a.x_sub = x_sub ? 1 : 0;
 #if defined(R50_STAMP)
     a.dbg = g_dbg;
 #endif
@@ -910,7 +913,7 @@ hipError_t launch_bneck_block2(const void* t1, int n, const void* w2, const floa
 // layer1.1 / .2 bottleneck body in one launch (kernels.h: bneck_block1_kernel): conv2 + conv3 + identity + ReLU + the next conv1 (c1 = 64 or 128)
 hipError_t launch_bneck_block1(const void* t1, int n, const void* w2, const float* b2, const void* w3, const float* b3, const void* res,
                                void* out, const void* w1, int c1, const float* b1, void* y1n, hipStream_t s, int et = 0,
-                               const void* wd = nullptr, const float* bd = nullptr) {
+                               const void* wd = nullptr, const float* bd = nullptr, bool out_sub = false) {
     if (!t1 || !w2 || !b2 || !w3 || !b3 || !res || !out || !w1 || !b1 || !y1n || n <= 0 || (long long)n * 3136 * 512 >= (1ll << 31)) return hipErrorInvalidValue;
     if (c1 != 64 && c1 != 128) return hipErrorInvalidValue;
     if ((wd == nullptr) != (bd == nullptr) || (wd && c1 != 64)) return hipErrorInvalidValue;       // downsample form: layer1.0 (next conv1 256 -> 64)
@@ -923,7 +926,7 @@ hipError_t launch_bneck_block1(const void* t1, int n, const void* w2, const floa
     Block1Args a;
     a.t1 = (const __bf16*)t1; a.w2 = (const __bf16*)w2; a.b2 = b2; a.w3 = (const __bf16*)w3; a.b3 = b3; a.res = (const __bf16*)res;
     a.out = (__bf16*)out; a.w1 = (const __bf16*)w1; a.b1 = b1; a.y1n = (__bf16*)y1n; a.N = n; a.n_tiles = 14 * n;
-    a.wd = (const __bf16*)wd; a.bd = bd;
+    a.wd = (const __bf16*)wd; a.bd = bd; a.out_sub = out_sub ? 1 : 0;
     const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
     constexpr size_t lds = 11 * 32 * 128 + 3 * 224 * 128 + 3 * 8192 + (448 + 256) * 4;       // 158,464 (kernels.h: LDS map; bd behind b1)
     void (*kern)(const Block1Args);
@@ -1269,6 +1272,7 @@ after_pool:
     int cur = 1, hh = 56, ww = 56;
     int pre_t1 = stem_c1 ? 2 : -1;      // buffer that already holds the coming block's conv1 output (fused tail / stem), or -1
     bool layer1_out_fp8 = false;        // fp8 mode: layer1's output was written as e4m3 by its last conv's epilogue
+    bool cur_sub = false;               // buf[cur] holds only the even rows / columns of the block output (layer1.2 with option "sub_out")
     size_t li = 1;
     for (int si = 0; si < 4; ++si) {
         const int blocks = kStages[si][1];
@@ -1283,6 +1287,7 @@ after_pool:
                 if (i != cur && i != pre_t1) fr[nf++] = i;
             const bool have_t1 = (pre_t1 >= 0);
             pre_t1 = -1;
+            if (cur_sub && !(si == 1 && b == 0)) return fail(h, R50_ERR_STATE, "internal: a sub-sampled block output reached a block that reads the full tensor");
             const std::string p = "layer" + std::to_string(si + 1) + "." + std::to_string(b);
             const ConvLayer& c1 = h->convs[li];
             const ConvLayer& c2 = h->convs[li + 1];
@@ -1371,9 +1376,16 @@ after_pool:
                 }
                 const double m = (double)n * 3136.0;
                 EvRec rb{};
+                // layer1.2: the block output is read again only at its even rows and columns (layer2.0's stride-2 downsample conv, inside the chained
+                // transition tail; layer2.0.conv1 is computed in this launch): write just those -- 103 MB instead of 411 MB at batch 256.  Only when
+                // the consumer that understands the compact tensor is the one that will run (the conditions of the catchain branch below).
+                const bool sub = h->sub_out && nx->cout == 128 && b == blocks - 1 && h->fuse_ds_cat && h->cat_w[1] && h->fuse_cat_chain && h->catchain_wp &&
+                                 (h->precision == R50_PREC_BF16 || h->precision == R50_PREC_FP16);
                 prof_begin(h, s, rb, PC_BLOCK2, 2.0 * m * (64.0 * 576 + 256.0 * 64 + (double)nx->cout * 256),
-                           2.0 * (m * (64.0 + 256 + 256 + nx->cout) + 64.0 * 576 + 256.0 * 64 + (double)nx->cout * 256), (int)(&c2 - &h->convs[0]));
-                e = launch_bneck_block1(buf[fr[0]], n, c2.w, c2.bias, c3.w, c3.bias, buf[cur], buf[fr[3]], nx->w, nx->cout, nx->bias, buf[fr[1]], s, et);
+                           2.0 * (m * (64.0 + 256 + (sub ? 64.0 : 256.0) + nx->cout) + 64.0 * 576 + 256.0 * 64 + (double)nx->cout * 256), (int)(&c2 - &h->convs[0]));
+                e = launch_bneck_block1(buf[fr[0]], n, c2.w, c2.bias, c3.w, c3.bias, buf[cur], buf[fr[3]], nx->w, nx->cout, nx->bias, buf[fr[1]], s, et,
+                                        nullptr, nullptr, sub);
+                cur_sub = sub;
                 prof_end(h, s, rb);
                 if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_block1 launch (" + c2.conv_key + "): " + hipGetErrorString(e));
                 pre_t1 = fr[1];
@@ -1455,7 +1467,8 @@ after_pool:
                 EvRec rt{};
                 prof_begin(h, s, rt, PC_CATCHAIN, 2.0 * m * (512.0 * 384 + 128.0 * 512), 2.0 * (m * (128.0 + 256 + 512 + 128) + 512.0 * 384 + 128.0 * 512),
                            (int)(&c3 - &h->convs[0]));
-                e = launch_bneck_catchain(buf[fr[1]], buf[cur], n, 28, h->catchain_wp, h->cat_bias[1], outb, nx->bias, buf[fr[0]], s, et);
+                e = launch_bneck_catchain(buf[fr[1]], buf[cur], n, 28, h->catchain_wp, h->cat_bias[1], outb, nx->bias, buf[fr[0]], s, et, cur_sub);
+                cur_sub = false;
                 prof_end(h, s, rt);
                 if (e != hipSuccess) return fail(h, R50_ERR_HIP, "bneck_catchain launch (" + c3.conv_key + "): " + hipGetErrorString(e));
                 h3 = h2; w3 = w2;
@@ -1906,6 +1919,7 @@ int r50_set_option(r50_handle* h, const char* key, int64_t value) {
     else if (k == "fuse_tail") h->fuse_tail = value ? 1 : 0;
     else if (k == "fuse_tail3") h->fuse_tail3 = value ? 1 : 0;
     else if (k == "fuse_cat_chain") h->fuse_cat_chain = value ? 1 : 0;
+    else if (k == "sub_out") h->sub_out = value ? 1 : 0;
     else if (k == "fuse_tail3_last") h->fuse_tail3_last = value ? 1 : 0;
     else if (k == "tail3_bp") { if (value < 0 || value > 112) return fail(h, R50_ERR_INVALID, "tail3_bp must be 0 .. 112"); g_tail3_bp = (int)value; }
     else if (k == "fuse_fp8_handover") h->fuse_fp8_handover = value ? 1 : 0;
@@ -1944,6 +1958,7 @@ int r50_get_option(r50_handle* h, const char* key, int64_t* value) {
     else if (k == "tail3_bp") *value = g_tail3_bp;
     else if (k == "use_g8") *value = g_use_g8;
     else if (k == "fuse_cat_chain") *value = h->fuse_cat_chain;
+    else if (k == "sub_out") *value = h->sub_out;
     else if (k == "fuse_tail3_last") *value = h->fuse_tail3_last;
     else if (k == "fuse_fp8_handover") *value = h->fuse_fp8_handover;
     else if (k == "fuse_stem_c1") *value = h->fuse_stem_c1;

@@ -112,6 +112,8 @@ int r50_forward_layer(r50_handle* h, const float* x_nchw_f32_dev, int n, const c
  * same bits),
  * "fuse_cat_chain" (layer2.0: conv3 + downsample + ReLU as one two-source conv chained with layer2.1.conv1 in one launch,
  * bneck_catchain_kernel; default 1; same bits),
+ * "sub_out" (layer1.2 stores only the even rows and columns of its output, the ones layer2.0's stride-2 downsample conv reads -- layer2.0.conv1
+ * is computed in the same launch; default 1; needs "fuse_block1" >= 2 and "fuse_cat_chain"; same features; debug taps always see full tensors),
  * "fuse_block2" (layer2.1-.3: conv2 + conv3 + identity + ReLU [+ the next conv1] in one launch, t2 kept in LDS; default 1; needs
  * "fuse_tail"; same bits),
  * "fuse_fp8_handover" (R50_PREC_FP8: layer1's output quantised to e4m3 in layer1.2.conv3's epilogue instead of in a pass of its

@@ -247,6 +247,36 @@ def test_default_fusions_give_the_bits_of_plain_launches(lib_built, precision):
     assert float((f_tails - f_plain).abs().max()) < 0.05 * float(f_plain.abs().max())      # (bneck_tail2: within rounding, not bit for bit)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("n", [1, 5, 37])
+def test_sub_sampled_layer1_output_gives_the_same_features(lib_built, precision, n):
+    """layer1.2 stores only the even rows / columns of its block output (option "sub_out", the default): its two readers are layer2.0.conv1
+    (computed in the same launch) and layer2.0's stride-2 downsample conv (inside bneck_catchain_kernel, which then reads the compact
+    tensor).  The features must be the bits of the run that writes the full tensor; and with the chained transition tail turned off
+    the full tensor must be written again (the compact form has no other reader)."""
+    from implementation_phd_lab_vision_amd.backbone import ResNet50Backbone
+    from implementation_phd_lab_vision_amd.weights import synthetic_frames
+    x = synthetic_frames(n, seed=91).to("cuda:0")
+    bb = ResNet50Backbone(seed=0, max_batch=n, precision=precision).to("cuda:0").eval()
+    try:
+        assert bb.get_option("sub_out") == 1
+        f_sub = bb.features(x).clone()
+        bb.set_option("sub_out", 0)
+        f_full = bb.features(x).clone()
+        bb.set_option("sub_out", 1)
+        bb.set_option("fuse_cat_chain", 0)            # layer2.0 through the two-source igemm launch: needs (and gets) the full tensor
+        f_nochain = bb.features(x).clone()
+        bb.set_option("fuse_cat_chain", 1)
+        tap = bb.layer(x, "layer1.2").clone()         # debug taps see full tensors
+        f_again = bb.features(x).clone()
+    finally:
+        bb.close()
+    assert torch.isfinite(f_full).all()
+    assert torch.equal(f_sub, f_full), f"max |diff| {float((f_sub - f_full).abs().max())}"
+    assert torch.equal(f_nochain, f_full) and torch.equal(f_again, f_full)
+    assert tuple(tap.shape) == (n, 56, 56, 256)
+
+
 def test_fused_bottleneck_tail_equals_unfused(setup):
     """conv3 + identity + ReLU + the next block's conv1 in one kernel.  layer1 (pixels split over the waves): bit
     for bit what the two igemm launches give.  layer2 (channels split over the waves, second conv summed in eight
