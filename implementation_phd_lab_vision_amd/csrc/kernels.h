@@ -1472,7 +1472,6 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
         const int w_ph0 = (fq ^ (fr & 7)) << 4;                         // kk = 0; kk = 1 is ^ 64
         const int cout_lane = wave_c * MR * 16 + 8 * fq;
         // this lane's pixel of each of the wave's blocks: padded position at tap (0,0) (block 13 of the second half does not exist)
-        const int p_lane = 16 * 7 * wave_p + fr;                          // this lane's pixel of block 0 (pixel of block j: + 16 j)
         int q0[7];
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
@@ -1483,7 +1482,7 @@ __global__ __launch_bounds__(768) void conv3x3_xres_kernel(const ConvArgs a) {
             q0[j] = panel * PP + r * PW + c;
         }
         f32x4 acc[MR][7];
-        int c_buf = 0, x_par = 0;
+        int c_buf = 0;
         // RB: see the kernel's head.  Ring slot of tap s is s % 3 (nine steps per chunk, three stages), so with the nine taps unrolled every LDS
         // address of the K loop is a lane constant + an immediate.
         R50_STAMP_DECL
@@ -2379,7 +2378,6 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
         __builtin_amdgcn_sched_barrier(0);        // a scheduling region per step
     };
     bf16x8 wA[4], wB[4], xq[NR];
-    using YES = std::true_type;
     using NO = std::false_type;
 
     if (wave < 4) {
@@ -2419,7 +2417,6 @@ __global__ __launch_bounds__(512) void bneck_tail3p_kernel(const Tail3Args a) {
         //     than the previous chunk's E phase.
         u32x4 r0[NR], r1[NR];
         bf16x8 wq[4][4];
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.M * (COUT * 2u), 0x00020000);
         tile_rows(first, rv);
         tile_rows(first + grid, rvn);
         issue_t2(first);
@@ -4903,7 +4900,6 @@ __device__ __forceinline__ void split_bf16(float v, unsigned& head16, unsigned& 
 template <typename TIN>
 __global__ __launch_bounds__(256) void stem_pack_split_kernel(const TIN* __restrict__ x, u32x2* __restrict__ xp_head,
                                                               u32x2* __restrict__ xp_tail, int n_img) {
-    constexpr int ET = 0;      // the (head, tail) pair format is bf16-specific
     const long long total = (long long)n_img * STEM_HP * STEM_WP;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
